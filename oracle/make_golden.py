@@ -1,0 +1,228 @@
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF (imported from /root/reference).
+
+Build-container only (the reference cannot travel).  Usage:
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+What runs: the reference's own Python (lcaonet.model.LCAONet, lcaonet.nn.rbf / shbf / cutoff,
+lcaonet.atomistic) with `oracle/standins/` ahead of it on sys.path for the three third-party
+packages this image lacks (torch_geometric, torch_scatter, torch_sparse; see
+oracle/standins/README.md).  The fixtures hold data only: inputs, the reference's state_dict,
+and the reference's outputs / intermediates.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "standins"))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+import torch.nn.functional as F  # noqa: E402
+import lcaonet.model.lcaonet as ref_mod  # noqa: E402
+from lcaonet.atomistic import elec as ref_elec  # noqa: E402
+from lcaonet.atomistic.info import ElecInfo  # noqa: E402
+from lcaonet.model import LCAONet  # noqa: E402
+from lcaonet.nn.cutoff import CosineCutoff, EnvelopeCutoff, PolynomialCutoff  # noqa: E402
+from lcaonet.nn.rbf import HydrogenRadialBasis, SphericalBesselRadialBasis  # noqa: E402
+from lcaonet.nn.shbf import SphericalHarmonicsBasis  # noqa: E402
+from torch_geometric.data import Data  # noqa: E402  (stand-in)
+
+from lcaonet_amd.data.synthetic import random_periodic_cells, reference_fixture_graph  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def tables():
+    """Static atomistic tables (data) + ElecInfo slicing answers for a sweep of arguments."""
+    d = dict(
+        NL_LIST=ref_elec.NL_LIST.numpy(), MAX_ELEC_IDX=ref_elec.MAX_ELEC_IDX.numpy(),
+        ELEC_TABLE=ref_elec.ELEC_TABLE.numpy(), VALENCE_TABLE=ref_elec.VALENCE_TABLE.numpy(),
+    )
+    cases = []
+    for max_z in [1, 2, 3, 4, 5, 10, 11, 12, 18, 20, 30, 36, 38, 48, 54, 56, 57, 80, 86, 88, 96]:
+        for max_orb in [None, "1s", "3s", "4p", "6s", "6d"]:
+            for min_orb in [None, "2s"]:
+                for npo in [1, 2]:
+                    ei = ElecInfo(max_z, max_orb, min_orb, npo)
+                    cases.append(dict(max_z=max_z, max_orb=max_orb, min_orb=min_orb, n_per_orb=npo, n_orb=ei.n_orb,
+                                      min_orb_idx=ei.min_orb_idx, nl=ei.nl_list.tolist(),
+                                      max_elec_idx=ei.max_elec_idx.tolist(),
+                                      elec_sum=int(ei.elec_table.sum()), val_sum=int(ei.valence_table.sum())))
+    d["elecinfo_cases"] = np.array(json.dumps(cases))
+    np.savez_compressed(os.path.join(OUT, "atomistic_tables.npz"), **d)
+
+
+def basis():
+    """rb on a radial grid (all 18 orbitals, 3 cutoffs, 2 radii, both bases) and shb on a cos grid; fp32 + fp64."""
+    d = {}
+    ei = ElecInfo(96, None, None, 1)
+    for rc in (5.0, 6.0):
+        r64 = torch.linspace(0.05, 1.1 * rc, 384, dtype=torch.float64)
+        d[f"r_rc{rc:g}"] = r64.numpy()
+        for cname, ccls in (("envelope", EnvelopeCutoff), ("polynomial", PolynomialCutoff), ("cosine", CosineCutoff)):
+            cn = ccls(rc)
+            for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+                r = r64.to(dt)
+                d[f"cutoff_{cname}_rc{rc:g}_{tag}"] = cn(r).numpy()
+                d[f"hydrogen_{cname}_rc{rc:g}_{tag}"] = HydrogenRadialBasis(rc, ei, cn)(r).numpy()
+                d[f"bessel_{cname}_rc{rc:g}_{tag}"] = SphericalBesselRadialBasis(rc, ei, cn)(r).numpy()
+    c64 = torch.linspace(-1, 1, 384, dtype=torch.float64)
+    d["costheta"] = c64.numpy()
+    sh = SphericalHarmonicsBasis(ei)
+    d["shb_f32"] = sh(c64.float()).numpy()
+    d["shb_f64"] = sh(c64).numpy()
+    d["nl"] = ei.nl_list.numpy()
+    np.savez_compressed(os.path.join(OUT, "basis_tables.npz"), **d)
+
+
+class Recorder:
+    """Records the reference's in-layer intermediates by wrapping `scatter` and `F.normalize`
+    as seen from lcaonet/model/lcaonet.py (call order per layer: normalize(T,V), scatter->E,
+    normalize(E,V), scatter->N)."""
+
+    def __init__(self):
+        self.scatter_out, self.norm_out = [], []
+
+    def __enter__(self):
+        self._s, self._n = ref_mod.scatter, F.normalize
+
+        def scatter(*a, **k):
+            o = self._s(*a, **k)
+            self.scatter_out.append(o.detach())
+            return o
+
+        def normalize(*a, **k):
+            o = self._n(*a, **k)
+            self.norm_out.append(o.detach())
+            return o
+
+        ref_mod.scatter = scatter
+        F.normalize = normalize
+        return self
+
+    def __exit__(self, *exc):
+        ref_mod.scatter, F.normalize = self._s, self._n
+
+
+def randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
+            m.bias.data.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+        if isinstance(m, torch.nn.Linear) and m.bias is not None:
+            m.bias.data.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+
+
+def run_case(name, graph_dict, kwargs, seed=0, train=False, keep_triplets=False, dtypes=("f32", "f64")):
+    torch.manual_seed(seed)
+    model = LCAONet(**kwargs)
+    randomise_bn(model, seed + 1)
+    model.train(train)
+    d = {"cfg": np.array(json.dumps({**{k: (v.tolist() if torch.is_tensor(v) else v) for k, v in kwargs.items()},
+                                     "training": train}))}
+    for k, v in graph_dict.items():
+        d["in/" + k] = v.numpy()
+    for k, v in model.state_dict().items():
+        d["sd/" + k] = v.numpy()
+    for tag in dtypes:
+        dt = torch.float32 if tag == "f32" else torch.float64
+        m = model.to(dt)
+        g = Data(**{k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in graph_dict.items()})
+        cap = {}
+        hooks = [
+            m.rbf.register_forward_hook(lambda mod, i, o: cap.__setitem__("rb", o.detach())),
+            m.shbf.register_forward_hook(lambda mod, i, o: cap.__setitem__("shb", o.detach())),
+            m.emb_layer.register_forward_hook(lambda mod, i, o: cap.update(x0=o[0].detach(), cst=o[1].detach())),
+        ]
+        for li, layer in enumerate(m.int_layers):
+            hooks.append(layer.register_forward_hook(
+                lambda mod, i, o, li=li: cap.__setitem__(f"x{li + 1}", o.detach())))
+        with Recorder() as rec:
+            need_grad = kwargs.get("regress_forces", False) and not kwargs.get("direct_forces", True)
+            ctx = torch.enable_grad() if (need_grad or train) else torch.no_grad()
+            with ctx:
+                out = m(g)
+        for h in hooks:
+            h.remove()
+        L = kwargs.get("n_interaction", 3)
+        for li in range(L):
+            cap[f"three_body_w{li + 1}"] = rec.scatter_out[2 * li]
+            cap[f"lcao_w{li + 1}"] = rec.norm_out[2 * li + 1]
+        if isinstance(out, tuple):
+            cap["out"], cap["force"] = out[0].detach(), out[1].detach()
+        else:
+            cap["out"] = out.detach()
+        cap["edge_dist"], cap["edge_vec"] = g["edge_dist"].detach(), g["edge_vec"].detach()
+        if keep_triplets:
+            cap["idx_k_3b"], cap["edge_idx_ks_3b"] = g["idx_k_3b"], g["edge_idx_ks_3b"]
+            cap["edge_idx_st_3b"], cap["angles_3b"] = g["edge_idx_st_3b"], g["angles_3b"].detach()
+        else:
+            cap["n_triplets"] = torch.tensor(g["idx_k_3b"].numel())
+            cap.pop("shb")  # (T, D): too large for a fixture; covered by basis_tables + fixture graph
+        E = cap["cst"].shape[0]
+        if E > 64:
+            cap["cst_head"] = cap.pop("cst")[:64]
+        for k, v in cap.items():
+            d[f"{tag}/{k}"] = v.numpy()
+        model = m
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **d)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  out={d['f32/out'].ravel()[:3]}")
+
+
+def graph_to_dict(g):
+    return {k: g[k] for k in g.keys()}
+
+
+def main():
+    tables()
+    basis()
+    fx = graph_to_dict(reference_fixture_graph())
+    small = dict(emb_size=16, emb_size_coeff=16, emb_size_conv=10, out_size=1, n_interaction=3, cutoff=6.0)
+    cases = {
+        "fixture_default": small,
+        "fixture_valence": {**small, "add_valence": True},
+        "fixture_valence_extend": {**small, "add_valence": True, "extend_orb": True, "cutoff": 2.0,
+                                   "cutoff_net": "polynomial"},
+        "fixture_n_per_orb2": {**small, "n_per_orb": 2},
+        "fixture_max_orb4p": {**small, "n_per_orb": 2, "max_orb": "4p", "max_z": 10},
+        "fixture_bessel": {**small, "rbf_type": "sphericalbessel", "cutoff": 2.0},
+        "fixture_cosine_noelec_mean": {**small, "cutoff_net": "cosine", "elec_to_node": False, "is_extensive": False,
+                                       "mean": torch.tensor([1.0])},
+        "fixture_atomref": {**small, "atomref": torch.linspace(-1, 1, 37).unsqueeze(1), "mean": torch.tensor([0.5]),
+                            "out_size": 1},
+        "fixture_dims": dict(emb_size=10, emb_size_coeff=32, emb_size_conv=16, out_size=2, n_interaction=2,
+                             cutoff=6.0, max_z=84),
+        "fixture_direct_forces": {**small, "regress_forces": True, "direct_forces": True},
+        "fixture_autograd_forces": {**small, "regress_forces": True, "direct_forces": False},
+    }
+    for i, (name, kw) in enumerate(cases.items()):
+        run_case(name, fx, kw, seed=10 + i, keep_triplets=True)
+    # random periodic cells, every edge <= 0.99 * model cutoff
+    g1 = graph_to_dict(random_periodic_cells(2, 12, 6.0, 0.99 * 5.0, max_z=36, seed=7))
+    run_case("cells_h32", g1, dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=5.0), 21)
+    run_case("cells_h16_train", g1, dict(emb_size=16, emb_size_coeff=16, emb_size_conv=16, n_interaction=2,
+                                         cutoff=5.0), 22, train=True)
+    g2 = graph_to_dict(random_periodic_cells(3, 10, 6.5, 0.99 * 6.0, max_z=84, seed=8, max_neighbors=20))
+    run_case("cells_z84_valence", g2, dict(emb_size=16, emb_size_coeff=24, emb_size_conv=16, n_interaction=2,
+                                           cutoff=6.0, max_z=84, add_valence=True, regress_forces=True), 23)
+    # a graph WITH edges in the last 1 % shell, for the conditioning test (fp32 vs fp64 disagree here)
+    g3 = graph_to_dict(random_periodic_cells(2, 12, 6.0, 5.0, max_z=36, seed=7))
+    run_case("cells_h32_fullshell", g3, dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2,
+                                             cutoff=5.0), 21)
+
+
+if __name__ == "__main__":
+    main()
