@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py — forward edges/s of the LCAOConv stack on the BASELINE config-2 workload, one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                 (N > 1, one rank per GPU, RCCL)
+
+A step = one `model(batch)` forward (eval, fp32) over one resident batch: geometry, radial basis, embedding,
+L interaction layers (coefficient MLP + three-body + two-body + node scatter), output head.  Weak scaling: every
+rank owns its own batch of whole crystals (cells are independent graphs, so the data path has no collective);
+`value` = edges processed by all ranks / max-over-ranks time.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md: "Chip-level parameters")
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (generator kwargs, model kwargs)
+    "cfg2": (dict(n_cells=1000, n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, max_z=36),
+             dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=5.0)),
+    "cfg2-small": (dict(n_cells=64, n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, max_z=36),
+                   dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=5.0)),
+}
+
+
+def build_model(kw, seed, dev):
+    from lcaonet_amd.model import LCAONet
+
+    torch.manual_seed(seed)
+    m = LCAONet(**kw).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    for mod in m.modules():  # BASELINE/SURVEY §8d: BN running stats mean~N(0,0.1), var~U(0.5,1.5)
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    return m.to(dev)
+
+
+def cpu_baseline(max_seconds: float = 25.0) -> dict:
+    """The CPU oracle (a literal-dataflow restatement of the reference, oracle/restatement.py) timed on this box's
+    host cores on BASELINE config 1 — the reference's own CPU-runnable case."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import LCAONet
+    from oracle import restatement as O
+
+    kw = dict(emb_size=64, n_interaction=2, rbf_type="hydrogen", cutoff=5.0)
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in LCAONet(**kw).eval().state_dict().items()}
+    g = random_periodic_cells(32, 20, 7.4, 0.99 * 5.0, seed=1234).to_dict()
+    E = g["edge_index"].shape[1]
+    cfg = O.OracleConfig(**kw)
+    cores = torch.get_num_threads()
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        O.forward(sd, cfg, g)  # warm-up
+        while len(times) < 5 and (time.time() - t_start) < max_seconds:
+            t0 = time.time()
+            O.forward(sd, cfg, g)
+            times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": E / med, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"BASELINE config 1: LCAONet(emb_size=64,n_interaction=2,cutoff=5.0) forward on 32x20-atom cells, "
+                      f"E={E}, median of {len(times)} runs, torch CPU threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=-1, help="-1 auto, 0 generic kernels only, 1 force fused")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from lcaonet_amd import ops
+    from lcaonet_amd.data.synthetic import jittered_cubic_cells
+
+    gen_kw, model_kw = WORKLOADS[args.workload]
+    model = build_model(model_kw, 1234, dev)                      # identical weights on every rank
+    batch = jittered_cubic_cells(seed=1234 + rank, device=dev, **gen_kw)  # this rank's own crystals
+    E = int(batch["edge_index"].shape[1])
+    N = int(batch["z"].numel())
+    fused = None if args.fused < 0 else bool(args.fused)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(batch, fused=fused)
+        barrier()
+        t0 = time.perf_counter()
+        with ops.profile() as prof:
+            for _ in range(args.steps):
+                out = model(batch, fused=fused)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            ksum = prof.summary()
+    assert bool(torch.isfinite(out).all())
+
+    t = torch.tensor([elapsed, float(E)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, e_total = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, e_total = elapsed, float(E)
+
+    if rank == 0:
+        D = model.elec_info.n_orb
+        C, V, L, n_l = model.emb_size_coeff, model.emb_size_conv, model.n_interaction, model.n_l
+        # dominant kernel: lcao_coeff_mlp_contract (f_coeffs on the matrix cores).  Algorithmic work per launch
+        # (SURVEY.md §8d row "f_coeffs"): 2*D*(C*V + V*V) flop per edge; HBM 4*D*C read + 4*(n_l+1)*V write per edge.
+        name = "lcao_coeff_mlp_contract"
+        roof = None
+        if name in ksum:
+            calls, ms = ksum[name]
+            per_launch_ms = ms / calls
+            flop = 2.0 * D * (C * V + V * V) * E
+            achieved = flop / (per_launch_ms * 1e-3) / 1e12
+            roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(per_launch_ms, 4), "launches": calls,
+                    "algorithmic_bytes_per_launch": (4 * D * C + 4 * D + 4 * (n_l + 1) * V) * E}
+        # the HBM-bound group of the north star ("edge-basis + scatter path"): three-body kernel
+        roof_hbm = None
+        if "lcao_triplet_sum" in ksum:
+            calls, ms = ksum["lcao_triplet_sum"]
+            per_launch_ms = ms / calls
+            byts = (4 * n_l * V + 4 * V + 12 + 8) * E + 4 * V * N  # A rows + tbw write + uvec/idx + gate rows
+            gbs = byts / (per_launch_ms * 1e-3) / 1e9
+            roof_hbm = {"kernel": "lcao_triplet_sum", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(per_launch_ms, 4), "launches": calls,
+                        "algorithmic_bytes_per_launch": byts}
+        line = {
+            "metric": "edges/sec forward (LCAOConv stack), 1M-edge synthetic batch",
+            "value": e_total * args.steps / elapsed_max, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {gen_kw['n_cells']} jittered {gen_kw['n_side']}^3 simple-cubic "
+                                   f"crystals per GPU (N={N}, E={E} per GPU), graph cutoff {gen_kw['cutoff_graph']}, "
+                                   f"LCAONet(emb_size={model.emb_size}, coeff={C}, conv={V}, n_interaction={L}, D={D}, "
+                                   f"cutoff={model.cutoff}), random-init weights, eval, whole forward",
+                       "edges_per_gpu": E, "nodes_per_gpu": N, "sharding": "whole crystals per rank, no collective"},
+            "roofline": roof, "roofline_hbm": roof_hbm,
+            "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][1])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/* lcaonet_hip.h — C ABI of liblcaonet_hip.so: LCAONet's per-edge interaction hot path on MI355X (gfx950).
+ *
+ * The reference (nmdl-mizo/lcaonet v0.0.3) is pure Python: it has no FFI.  Its boundary for this path is
+ * the nn.Module API; each entry point below replaces the ATen / torch_scatter op group of one reference
+ * function (cited as file:line relative to the reference root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers into caller-owned buffers (PyTorch-ROCm tensors); the library never allocates,
+ *     frees, or synchronises; work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - float data is fp32, row-major, contiguous unless a leading dimension is given.
+ *   - `int64_t` index arrays are the reference's own (edge_index, batch, z); `int32_t` arrays are the
+ *     library's internal CSR built by lcao_build_csr_* (E, N < 2^31, checked).
+ *   - return 0 on success; <0 = LCAO_ERR_*; >0 = hipError_t from the launch.  lcao_error_string() decodes.
+ *   - re-entrant, no global state, one host thread per device.
+ *
+ * Edge spaces: "orig" = the caller's edge order; "p" = edges stably sorted by centre node idx_s
+ * (`order[p]` = orig edge id).  Per-edge work buffers (A, B, tbw, ...) live in p-space.
+ */
+#ifndef LCAONET_HIP_H
+#define LCAONET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCAO_ABI_VERSION 1
+
+#define LCAO_OK 0
+#define LCAO_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, size over 2^31) */
+#define LCAO_ERR_UNSUPPORTED (-2) /* shape outside what the kernel was built for (caller must not fall back silently) */
+
+enum { LCAO_ACT_NONE = 0, LCAO_ACT_SILU = 1, LCAO_ACT_SIGMOID = 2 };
+enum { LCAO_CUTOFF_ENVELOPE = 0, LCAO_CUTOFF_POLYNOMIAL = 1, LCAO_CUTOFF_COSINE = 2, LCAO_CUTOFF_NONE = 3 };
+enum { LCAO_RBF_HYDROGEN = 0, LCAO_RBF_BESSEL = 1 };
+
+/* per-orbital row of the radial table handed to lcao_radial_basis: LCAO_ORB_STRIDE floats
+ *   [0] zeta scale 2/(n*r0)   [1] normalisation C_nl   [2] l   [3] polynomial degree k=n-l-1
+ *   [4..10] integer polynomial coefficients c_0..c_6 (ascending powers)   [11] bessel frequency n*pi (divided by rc in the kernel) */
+#define LCAO_ORB_STRIDE 12
+#define LCAO_MAX_L 3
+
+int lcao_abi_version(void);
+const char* lcao_error_string(int code);
+
+/* a1  BaseMPNN.calc_atomic_distances (lcaonet/model/base.py:15-43)
+ * vec = pos[t]-pos[s] + shift @ lattice[batch[s]];  dist = |vec|;  uvec = vec/dist.   (orig order) */
+int lcao_edge_geometry(const float* pos, const int64_t* idx_s, const int64_t* idx_t, const float* shift,
+                       const float* lattice, const int64_t* batch /*nullable*/, int64_t n_edges,
+                       float* dist, float* uvec, void* stream);
+
+/* a4  {Envelope,Polynomial,Cosine}Cutoff.forward (lcaonet/nn/cutoff.py:32-34,41-43,62-67) */
+int lcao_cutoff(const float* r, int64_t n, int kind, float rc, float* out, void* stream);
+
+/* a5/a5'  HydrogenRadialBasis.forward / SphericalBesselRadialBasis.forward (lcaonet/nn/rbf.py:129-142,171-182)
+ * r (E) -> rb (E, D).  orb_table: device, D rows of LCAO_ORB_STRIDE floats. */
+int lcao_radial_basis(const float* r, int64_t n_edges, int n_orb, const float* orb_table, int rbf_kind,
+                      int cutoff_kind, float rc, float* rb, void* stream);
+
+/* a6  SphericalHarmonicsBasis.forward (lcaonet/nn/shbf.py:75-87): costheta (T) -> shb (T, D), Y_l^0, l = l_of_d[d] */
+int lcao_sph_basis(const float* costheta, int64_t n, int n_orb, const int32_t* l_of_d, float* shb, void* stream);
+
+/* a3  LCAONet.calc_3body_angles (lcaonet/model/lcaonet.py:432-433): cos[t] = uvec[e_st[t]] . uvec[e_ks[t]] */
+int lcao_triplet_angles(const float* uvec, const int64_t* e_st, const int64_t* e_ks, int64_t n_trip, float* cosv,
+                        void* stream);
+
+/* Dense layers on the path (lcaonet/nn/base.py:71-81 used at lcaonet.py:167,170,192,209,214,290,305):
+ * Y[m, n] = act( sum_k X[m,k] * W[n,k] + bias[n] ) + residual[m,n];  bias / residual nullable. */
+int lcao_dense(const float* X, int64_t ldx, const float* W, const float* bias, const float* residual, int64_t ldr,
+               float* Y, int64_t ldy, int64_t M, int K, int N, int act, void* stream);
+
+/* a8  torch_scatter.scatter(reduce="sum") over CONTIGUOUS segments (index sorted): out[i] = sum_{r in [ptr[i],ptr[i+1])} a[r]*b[r]
+ * (b nullable => plain segment sum).  Call sites lcaonet.py:189,208-213,293,307.  Deterministic (no atomics). */
+int lcao_segment_sum(const float* a, const float* b, const int32_t* ptr, int64_t n_seg, int width, float* out,
+                     void* stream);
+
+/* rows gather: out[i,:] = table[idx[i],:]  (x[idx_s], embedding lookups) */
+int lcao_gather_rows(const float* table, const int64_t* idx, int64_t n, int width, float* out, void* stream);
+/* out[i,:] = src[perm[i],:] with int32 perm */
+int lcao_permute_rows(const float* src, const int32_t* perm, int64_t n, int width, float* out, void* stream);
+
+/* lcaonet.py:173-183 + 200-203 restructured (exact reassociation): per edge p (p-space)
+ *   A [p,l,:] = sum_{d: l(d)=l} rb[e,d] * ( c[e,d,:] + m[e,d,:]*cv[e,d,:] )        (E, n_l, V)
+ *   B [p,:]   = sum_d rb[e,d] * c[e,d,:]                                          (E, V)
+ *   Bv[p,:]   = sum_d rb[e,d] * m[e,d,:]*cv[e,d,:]                                (E, V)  (valence only)
+ * with e = order[p] (order nullable = identity), cstf = f_coeffs(cst) of shape (E, D, Vt), Vt = V or 2V
+ * ([c | cv]); mask given by pointer + element strides (stride_v = 0 for the reference's expanded view). */
+int lcao_coeff_contract(const float* cstf, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                        const float* mask, int64_t mask_se, int64_t mask_sd, int64_t mask_sv, int64_t n_edges,
+                        int n_orb, int V, int n_l, int valence, float* A, float* B, float* Bv, void* stream);
+
+/* lcaonet.py:173-189 fused (a3 + a6 + contraction + F.normalize + sigmoid gate + segment-sum T->E), no T-sized
+ * tensor is ever written:  for edge p = (s->t):
+ *   tbw[p,:] = sum_{q in In(s), q != p} normalize( sum_l Y_l(u_p . u_q) A[q,l,:] ) * gate[src(q),:]
+ * gate = sigmoid(xk) (N,V); uvec in orig order; In(s) = in_pos[in_ptr[s] .. in_ptr[s+1]) (p-indices). */
+int lcao_triplet_sum(const float* A, const float* gate, const float* uvec, const int32_t* order,
+                     const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos, int64_t n_edges, int V,
+                     int n_l, float* tbw, void* stream);
+
+/* lcaonet.py:192-204: lw[p,:] = normalize( (1+ft[p,:V]) * B[p,:] [+ (1+ft[p,V:2V]) * Bv[p,:]] ) */
+int lcao_edge_combine(const float* ft, const float* B, const float* Bv, int64_t n_edges, int V, float* lw,
+                      void* stream);
+
+/* lcaonet.py:209 first f_node layer, split by linearity: h1[p,:] = SiLU( Ps[src_p[p],:] + Pt[dst_p[p],:] )
+ * where Ps = x W[:, :V]^T + b, Pt = x W[:, V:]^T are node-level products. */
+int lcao_pair_silu(const float* Ps, const float* Pt, const int32_t* src_p, const int32_t* dst_p, int64_t n_edges,
+                   int V, float* h1, void* stream);
+
+/* LCAOEmbedding/EmbedCoeffs (lcaonet.py:72, embed.py:235-249) in eval mode, species-table form:
+ *   cst[p,d,c] = scale[d,c] * FE[z_t,d,c] * (1 + U[z_s,c] + Vt[z_t,c]) + shift[d,c]
+ * z_s = z[src_p[p]], z_t = z[dst_p[p]] (z int64 atomic numbers, tables indexed by z). */
+int lcao_embed_coeffs(const float* FE, const float* U, const float* Vt, const float* scale, const float* shift,
+                      const int64_t* z, const int32_t* src_p, const int32_t* dst_p, int64_t n_edges, int n_orb, int C,
+                      float* cst, void* stream);
+
+/* Literal LCAOInteraction three-body operator with explicit triplet lists (lcaonet.py:173-188), for the
+ * operator-level API:  w[t,:] = normalize( sum_d rb[ks,d]*shb[t,d]*(c[ks,d,:] + m*cv[ks,d,:]) ) * sigmoid(xk[k[t],:]) */
+int lcao_triplet_literal(const float* cstf, const float* rb, const float* shb, const float* xk, int64_t ldxk,
+                         const int64_t* tri_k, const int64_t* e_ks, const float* mask, int64_t mask_se,
+                         int64_t mask_sd, int64_t mask_sv, int64_t n_trip, int n_orb, int V, int valence, float* w,
+                         void* stream);
+
+/* ---- MFMA fast paths (V, C multiples of 16; return LCAO_ERR_UNSUPPORTED otherwise) ------------------ */
+
+/* lcaonet.py:170 + the contraction above in ONE kernel: f_coeffs = SiLU(SiLU(cst W1^T) W2^T) is never
+ * written to HBM.  cst (E, D, C) orig order; W1 (V, C); W2 (Vt, V).  fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * gate/src_p nullable: when given, also writes Ag[p,l,:] = A[p,l,:] * gate[src_p[p],:] (may be NULL). */
+int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                            const float* valence_ed /* (E,D) orig order, nullable */, const float* W1,
+                            const float* W2, int64_t n_edges, int n_orb, int C, int V, int n_l, int valence,
+                            float* A, float* B, float* Bv, void* stream);
+
+/* lcaonet.py:192-204 + basis_weight (:209) in ONE kernel (no valence):
+ *   bw[p,:] = normalize( (1 + tbw[p,:] W3^T) * B[p,:] ) Wb^T          W3, Wb (V, V) */
+int lcao_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges, int V,
+                          float* bw, void* stream);
+
+/* lcaonet.py:209 second f_node layer + message product in ONE kernel:
+ *   msg[p,:] = bw[p,:] * SiLU( SiLU(Ps[src_p[p],:] + Pt[dst_p[p],:]) Wn2^T + bn2 ) */
+int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                           const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
+                           float* msg, void* stream);
+
+size_t lcao_lds_bytes_coeff_mlp(int C, int V, int valence);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCAONET_HIP_H */

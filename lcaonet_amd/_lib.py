@@ -1,0 +1,71 @@
+"""ctypes binding of liblcaonet_hip.so (the C ABI declared in include/lcaonet_hip.h).
+
+The product path has NO fallback: if the library is missing or fails to load, every op raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblcaonet_hip.so")
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/lcaonet_hip.h one to one
+SIGNATURES = {
+    "lcao_abi_version": [],
+    "lcao_error_string": [I],
+    "lcao_edge_geometry": [P, P, P, P, P, P, L, P, P, P],
+    "lcao_cutoff": [P, L, I, F, P, P],
+    "lcao_radial_basis": [P, L, I, P, I, I, F, P, P],
+    "lcao_sph_basis": [P, L, I, P, P, P],
+    "lcao_triplet_angles": [P, P, P, L, P, P],
+    "lcao_dense": [P, L, P, P, P, L, P, L, L, I, I, I, P],
+    "lcao_segment_sum": [P, P, P, L, I, P, P],
+    "lcao_gather_rows": [P, P, L, I, P, P],
+    "lcao_permute_rows": [P, P, L, I, P, P],
+    "lcao_coeff_contract": [P, P, P, P, P, L, L, L, L, I, I, I, I, P, P, P, P],
+    "lcao_triplet_sum": [P, P, P, P, P, P, P, L, I, I, P, P],
+    "lcao_edge_combine": [P, P, P, L, I, P, P],
+    "lcao_pair_silu": [P, P, P, P, L, I, P, P],
+    "lcao_embed_coeffs": [P, P, P, P, P, P, P, P, L, I, I, P, P],
+    "lcao_triplet_literal": [P, P, P, P, L, P, P, P, L, L, L, L, I, I, I, P, P],
+    "lcao_coeff_mlp_contract": [P, P, P, P, P, P, P, L, I, I, I, I, I, P, P, P, P],
+    "lcao_edge_lcao_weight": [P, P, P, P, L, I, P, P],
+    "lcao_edge_node_message": [P, P, P, P, P, P, P, L, I, P, P],
+    "lcao_lds_bytes_coeff_mlp": [I, I, I],
+}
+_RESTYPES = {"lcao_error_string": c_char_p, "lcao_lds_bytes_coeff_mlp": c_size_t}
+
+_lib = None
+
+
+class LcaoHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LcaoHipError(
+            f"{LIB_PATH} not found: build it with `python -m lcaonet_amd.build` (hipcc, gfx950). "
+            "lcaonet_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    if lib.lcao_abi_version() != 1:
+        raise LcaoHipError(f"ABI version mismatch: library {lib.lcao_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().lcao_error_string(code).decode()
+        raise LcaoHipError(f"{what} failed: {msg} (code {code})")

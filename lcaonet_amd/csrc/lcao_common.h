@@ -1,0 +1,84 @@
+// lcao_common.h — shared device helpers for the LCAONet hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lcaonet_hip.h"
+
+#define LCAO_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LCAO_CHECK_PTR(p) \
+  do {                    \
+    if ((p) == nullptr) return LCAO_ERR_INVALID; \
+  } while (0)
+#define LCAO_CHECK_SIZE(n) \
+  do {                     \
+    if ((n) < 0 || (n) >= (int64_t(1) << 31)) return LCAO_ERR_INVALID; \
+  } while (0)
+
+static inline int lcao_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? LCAO_OK : int(e);
+}
+
+static inline unsigned lcao_blocks(int64_t n, int per_block, int64_t cap = (int64_t(1) << 30)) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return unsigned(b);
+}
+
+__device__ __forceinline__ float lcao_silu(float x) {
+  // x * sigmoid(x); v_exp_f32 path (<= 2 ulp), safe at both tails (exp overflow -> x/inf = -0)
+  return x / (1.0f + __expf(-x));
+}
+__device__ __forceinline__ float lcao_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float lcao_act(float x, int act) {
+  if (act == LCAO_ACT_SILU) return lcao_silu(x);
+  if (act == LCAO_ACT_SIGMOID) return lcao_sigmoid(x);
+  return x;
+}
+
+// Y_l^0(cos theta), l <= 3: the closed forms the reference's sympy pipeline emits (lcaonet/nn/shbf.py:28-42,54-63)
+__device__ __forceinline__ float lcao_y_l0(float c, int l) {
+  switch (l) {
+    case 0: return 0.28209479177387814f;
+    case 1: return 0.48860251190292f * c;
+    case 2: return 0.94617469575756f * c * c - 0.31539156525252f;
+    default: return 0.373176332590115f * c * (5.0f * c * c - 3.0f);
+  }
+}
+
+// radial cutoff envelopes (lcaonet/nn/cutoff.py:32-34, 41-43, 62-67).  The envelope cancels catastrophically
+// towards rc, so its rounding pattern IS the result there: each power is a correctly rounded
+// pow (as torch's x**k), each product and sum is rounded separately (no FMA contraction), in the reference's order.
+__device__ __forceinline__ float lcao_cutoff_eval(float r, float rc, int kind) {
+#pragma clang fp contract(off)
+  if (kind == LCAO_CUTOFF_NONE) return 1.0f;  // user-defined envelope applied by the caller
+  if (!(r <= rc)) return 0.0f;
+  float x = r / rc;
+  if (kind == LCAO_CUTOFF_ENVELOPE) {
+    float t5 = -21.0f * powf(x, 5.0f), t6 = 35.0f * powf(x, 6.0f), t7 = -15.0f * powf(x, 7.0f);  // p = 5
+    return ((1.0f + t5) + t6) + t7;
+  } else if (kind == LCAO_CUTOFF_POLYNOMIAL) {
+    float t5 = 6.0f * powf(x, 5.0f), t4 = 15.0f * powf(x, 4.0f), t3 = 10.0f * (x * x * x);
+    return ((1.0f - t5) + t4) - t3;
+  } else {
+    float a = r * 3.14159265358979323846f;
+    return 0.5f * (cosf(a / rc) + 1.0f);
+  }
+}
+
+// sum across the 64 lanes of a wave, result in every lane (DPP within rows of 16, then readlane across rows)
+__device__ __forceinline__ float lcao_wave_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}

@@ -1,0 +1,411 @@
+"""LCAONet on MI355X: same constructor, forward(graph) contract, graph keys and state_dict names as the
+reference's lcaonet/model/lcaonet.py, with the per-edge interaction hot path executed by hand-written HIP
+kernels (liblcaonet_hip.so) in a restructured dataflow:
+
+  reference (lcaonet.py:130-216)                       here
+  ---------------------------------------------------  ------------------------------------------------------
+  f_coeffs(cst) -> (E,D,V) tensor, gathered per        lcao_coeff_mlp_contract: both f_coeffs layers on the
+  triplet as cks (T,D,V) = 65-80 GB at 1 M edges       matrix cores, folded with rb into A (E,n_l,V), B (E,V);
+                                                       (E,D,V) and every T-sized tensor never exist
+  rb[ks]*shb, einsum, normalize, sigmoid(xk[k]),       lcao_triplet_sum: per centre node, Y_l from unit vectors
+  scatter T->E                                         on the fly, exact L2 norm, gate, segmented sum
+  f_three, cst + cst*ft, einsum, normalize,            lcao_edge_lcao_weight (register-to-register MFMA chain)
+  basis_weight
+  f_node(cat[x_s, x_t]) * ..., scatter E->N            node-level split of f_node.0 (Ps/Pt), lcao_edge_node_message,
+                                                       lcao_segment_sum (edges sorted by centre, no atomics)
+
+Identities used (summation order changes only): shb[t,d] depends on d through l(d) alone (shbf.py:54-63), so
+sum_d rb*shb*c = sum_l Y_l * A[e',l,:];  cst + cst*ft summed against rb = B * (1 + ft);  a Dense on
+cat[x_s, x_t] = x_s W_a^T + x_t W_b^T.
+"""
+from __future__ import annotations
+
+from collections.abc import Callable
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+from ..atomistic.info import ElecInfo
+from ..data.keys import GraphKeys
+from ..nn.base import Dense, act_code, run_mlp
+from ..nn.cutoff import BaseCutoff
+from ..nn.embed import EmbedCoeffs, EmbedElec, EmbedNode, EmbedZ, ValenceMask
+from ..nn.post import PostProcess
+from ..nn.rbf import BaseRadialBasis
+from ..nn.scatter import csr_ptr, scatter
+from ..nn.shbf import SphericalHarmonicsBasis
+from ..utils.resolve import activation_resolver, cutoffnet_resolver, init_resolver, rbf_resolver
+from .base import BaseMPNN
+
+
+@dataclass
+class EdgeContext:
+    """Per-forward index structures in HBM (all int32, built without a host sync).
+
+    p-space = edges stably sorted by centre node (`order[p]` = caller's edge id); reference-produced graphs
+    (data/convert.py:135-153) are already grouped by centre, so `order` is then the identity."""
+    n_nodes: int
+    n_edges: int
+    order: Tensor      # (E)   p -> orig edge id
+    src_p: Tensor      # (E)   centre node of edge p (ascending)
+    dst_p: Tensor      # (E)   neighbour node of edge p
+    out_ptr: Tensor    # (N+1) edges p with centre s: [out_ptr[s], out_ptr[s+1])
+    in_ptr: Tensor     # (N+1) in-edge list of node s: in_pos[in_ptr[s] : in_ptr[s+1]]
+    in_pos: Tensor     # (E)   p-indices of edges k->s grouped by s, ordered by (k, orig id)
+    src_o: Tensor      # (E)   idx_s as int32, orig order
+    dst_o: Tensor      # (E)   idx_t as int32, orig order
+
+    @staticmethod
+    def build(edge_index: Tensor, n_nodes: int) -> "EdgeContext":
+        idx_s, idx_t = edge_index[0], edge_index[1]
+        E = idx_s.numel()
+        if E >= 2**31 or n_nodes >= 2**31:
+            raise ValueError("graph too large for int32 indexing on one GPU")
+        order = torch.argsort(idx_s, stable=True)
+        src_sorted = idx_s[order]
+        dst_sorted = idx_t[order]
+        in_pos = torch.argsort(dst_sorted, stable=True)
+        return EdgeContext(
+            n_nodes=n_nodes, n_edges=E,
+            order=order.to(torch.int32), src_p=src_sorted.to(torch.int32), dst_p=dst_sorted.to(torch.int32),
+            out_ptr=csr_ptr(src_sorted, n_nodes), in_ptr=csr_ptr(dst_sorted[in_pos], n_nodes),
+            in_pos=in_pos.to(torch.int32), src_o=idx_s.to(torch.int32), dst_o=idx_t.to(torch.int32),
+        )
+
+
+class LCAOEmbedding(nn.Module):
+    """Node vectors x (N, H) and per-edge coefficient vectors cst (E, D, C)  (reference lcaonet.py:30-74)."""
+
+    def __init__(self, emb_size: int, emb_size_coeff: int, elec_info: ElecInfo, max_z: int, use_elec: bool,
+                 extend_orb: bool, activation: nn.Module = nn.SiLU(),
+                 weight_init: Callable[[Tensor], Tensor] | None = None):
+        super().__init__()
+        self.emb_size = emb_size
+        self.emb_size_coeff = emb_size_coeff
+        self.use_elec = use_elec
+        self.max_z = max_z
+        self.z_embed = EmbedZ(emb_size + emb_size_coeff, max_z)
+        self.emb_size_node_e = emb_size if use_elec else 0
+        self.e_embed = EmbedElec(self.emb_size_node_e + emb_size_coeff, elec_info, extend_orb)
+        self.node_embed = EmbedNode(emb_size, emb_size, use_elec, self.emb_size_node_e, activation, weight_init)
+        self.coeff_embed = EmbedCoeffs(emb_size_coeff, emb_size_coeff, emb_size_coeff, elec_info.n_orb, activation,
+                                       weight_init)
+
+    def forward(self, z: Tensor, idx_s: Tensor, idx_t: Tensor) -> tuple[Tensor, Tensor]:
+        z_embed = self.z_embed(z)
+        node_z, coeff_z = torch.split(z_embed, [self.emb_size, self.emb_size_coeff], dim=-1)
+        e_embed = self.e_embed(z)
+        if self.use_elec:
+            node_e, coeff_e = torch.split(e_embed, [self.emb_size_node_e, self.emb_size_coeff], dim=-1)
+            x = self.node_embed(node_z, node_e)
+        else:
+            coeff_e = e_embed
+            x = self.node_embed(node_z)
+        cst = self.coeff_embed(coeff_z, coeff_e, idx_s, idx_t)
+        return x, cst
+
+    @torch.no_grad()
+    def forward_species(self, z: Tensor, ctx: EdgeContext) -> tuple[Tensor, Tensor]:
+        """Eval-mode forward through per-species tables: every quantity above is a function of the atomic
+        number (x) or of the (z_s, z_t) pair (cst), so the MLPs run on max_z rows and one fused kernel writes
+        cst = bn(fe[z_t] * (1 + f_z([zc[z_s], zc[z_t]])))  (embed.py:246-249), 4*D*C bytes per edge."""
+        assert not self.training
+        dev = z.device
+        zz = torch.arange(1, self.max_z + 1, device=dev)
+        z_embed = self.z_embed(zz)
+        node_z, coeff_z = torch.split(z_embed, [self.emb_size, self.emb_size_coeff], dim=-1)
+        e_embed = self.e_embed(zz)
+        if self.use_elec:
+            node_e, coeff_e = torch.split(e_embed, [self.emb_size_node_e, self.emb_size_coeff], dim=-1)
+            x_tab = self.node_embed(node_z.contiguous(), node_e.contiguous())
+        else:
+            coeff_e = e_embed
+            x_tab = self.node_embed(node_z.contiguous())
+        C = self.emb_size_coeff
+        ce = self.coeff_embed
+        wz = ce.f_z[0].weight.detach()
+        coeff_z = coeff_z.contiguous()
+        U = ops.dense(coeff_z, wz[:, :C].contiguous())   # centre half of f_z
+        Vt = ops.dense(coeff_z, wz[:, C:].contiguous())  # neighbour half
+        FE = run_mlp(ce.f_e, coeff_e.contiguous())        # (max_z, D, C)
+        bn = ce.bn
+        scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias.detach() - bn.running_mean * scale
+        pad = lambda t: torch.cat([torch.zeros_like(t[:1]), t], dim=0).contiguous()  # tables indexed by z (1-based)
+        x = ops.gather_rows(pad(x_tab), z)
+        cst = ops.embed_coeffs(pad(FE), pad(U), pad(Vt), scale.contiguous(), shift.contiguous(), z, ctx.src_o, ctx.dst_o)
+        return x, cst
+
+
+class LCAOInteraction(nn.Module):
+    """One LCAOConv message-passing layer (reference lcaonet.py:77-216); same parameters and names."""
+
+    def __init__(self, emb_size: int, emb_size_coeff: int, emb_size_conv: int, add_valence: bool = False,
+                 activation: nn.Module = nn.SiLU(), weight_init: Callable[[Tensor], Tensor] | None = None):
+        super().__init__()
+        self.emb_size = emb_size
+        self.emb_size_coeff = emb_size_coeff
+        self.emb_size_conv = emb_size_conv
+        self.add_valence = add_valence
+        self.node_weight = Dense(emb_size, 2 * emb_size_conv, True, weight_init)
+        out_size = 2 * emb_size_conv if add_valence else emb_size_conv
+        self.f_coeffs = nn.Sequential(  # no bias: zero coefficient vectors stay zero
+            Dense(emb_size_coeff, emb_size_conv, False, weight_init), activation,
+            Dense(emb_size_conv, out_size, False, weight_init), activation,
+        )
+        self.f_three = nn.Sequential(Dense(emb_size_conv, out_size, False, weight_init))
+        self.basis_weight = Dense(emb_size_conv, emb_size_conv, False, weight_init)
+        self.f_node = nn.Sequential(
+            Dense(2 * emb_size_conv, emb_size_conv, True, weight_init), activation,
+            Dense(emb_size_conv, emb_size_conv, True, weight_init), activation,
+        )
+        self.out_weight = Dense(emb_size_conv, emb_size, False, weight_init)
+
+    # ------------------------------------------------------------------ reference operator signature
+    @torch.no_grad()
+    def forward(self, x: Tensor, cst: Tensor, valence_mask: Tensor | None, rb: Tensor, shb: Tensor, idx_s: Tensor,
+                idx_t: Tensor, tri_idx_k: Tensor, edge_idx_ks: Tensor, edge_idx_st: Tensor) -> Tensor:
+        """Literal operator: arbitrary cst / shb / triplet lists as in the reference (lcaonet.py:130-142).
+        Materialises f_coeffs(cst) (E,D,V) and a (T,V) buffer like the reference does; LCAONet.forward uses
+        `forward_fused`, which does not."""
+        if self.add_valence and valence_mask is None:
+            raise ValueError("valence_mask must be provided when add_valence=True")
+        V, N, E = self.emb_size_conv, x.size(0), rb.size(0)
+        nw = self.node_weight(x)
+        xs, xk = nw[:, :V], nw[:, V:]
+        cstf = run_mlp(self.f_coeffs, cst)
+        w = ops.triplet_literal(cstf, rb, shb, xk, tri_idx_k, edge_idx_ks, valence_mask, V, self.add_valence)
+        three_body_w = scatter(w, edge_idx_st, dim=0, dim_size=E)
+        ft = run_mlp(self.f_three, three_body_w)
+        l0 = torch.zeros(rb.size(1), dtype=torch.int32, device=rb.device)
+        _, B, Bv = ops.coeff_contract(cstf, rb, None, l0, valence_mask, V, 1, self.add_valence)
+        lw = ops.edge_combine(ft, B, Bv)
+        xs = xs.contiguous()
+        h = run_mlp(self.f_node, torch.cat([xs[idx_s], xs[idx_t]], dim=-1))
+        msg = self.basis_weight(lw) * h
+        return self.out_weight(scatter(msg, idx_s, dim=0, dim_size=N), residual=x)
+
+    # ------------------------------------------------------------------ fused graph path
+    def _fusable(self, C: int) -> bool:
+        V = self.emb_size_conv
+        acts_silu = all(type(m) is nn.SiLU for m in (self.f_coeffs[1], self.f_coeffs[3], self.f_node[1], self.f_node[3]))
+        return acts_silu and V in ops.FUSED_WIDTHS and C == V
+
+    @torch.no_grad()
+    def forward_fused(self, x: Tensor, cst: Tensor, valence_ed: Tensor | None, rb: Tensor, uvec: Tensor,
+                      ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
+                      trace: dict | None = None) -> Tensor:
+        """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1."""
+        V = self.emb_size_conv
+        if fused is None:
+            fused = self._fusable(cst.shape[-1])
+        wn, bn_ = self.node_weight.weight.detach(), self.node_weight.bias.detach()
+        xs = ops.dense(x, wn[:V], bn_[:V])
+        gate = ops.dense(x, wn[V:], bn_[V:], ops.ACT_SIGMOID)           # sigmoid(xk), gathered per triplet
+        w1 = self.f_node[0].weight.detach()
+        Ps = ops.dense(xs, w1[:, :V].contiguous(), self.f_node[0].bias.detach())
+        Pt = ops.dense(xs, w1[:, V:].contiguous())
+        # coefficient MLP + radial contraction
+        if fused:
+            A, B, Bv = ops.coeff_mlp_contract(cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
+                                              self.f_coeffs[2].weight.detach(), n_l, self.add_valence)
+        else:
+            cstf = run_mlp(self.f_coeffs, cst)
+            A, B, Bv = ops.coeff_contract(cstf, rb, ctx.order, l_of_d, valence_ed, V, n_l, self.add_valence)
+        # three-body term
+        tbw = ops.triplet_sum(A, gate, uvec, ctx.order, ctx.src_p, ctx.in_ptr, ctx.in_pos)
+        if trace is not None:
+            trace["three_body_w"] = tbw  # p-space
+        # two-body term and messages
+        if fused and not self.add_valence:
+            bw = ops.edge_lcao_weight(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach())
+            msg = ops.edge_node_message(bw, Ps, Pt, ctx.src_p, ctx.dst_p, self.f_node[2].weight.detach(),
+                                        self.f_node[2].bias.detach())
+            agg = ops.segment_sum(msg, ctx.out_ptr)
+        else:
+            ft = run_mlp(self.f_three, tbw)
+            lw = ops.edge_combine(ft, B, Bv)
+            bw = self.basis_weight(lw)
+            code = act_code(self.f_node[1])
+            if code == ops.ACT_SILU:
+                h1 = ops.pair_silu(Ps, Pt, ctx.src_p, ctx.dst_p)
+            else:
+                h1 = self.f_node[1](Ps[ctx.src_p.long()] + Pt[ctx.dst_p.long()])
+            code2 = act_code(self.f_node[3])
+            h2 = self.f_node[2](h1, act=code2) if code2 is not None else self.f_node[3](self.f_node[2](h1))
+            agg = ops.segment_sum(bw, ctx.out_ptr, h2)
+        return self.out_weight(agg, residual=x)
+
+
+class LCAOOut(nn.Module):
+    """Output head (reference lcaonet.py:219-319): node MLP, per-graph reduction, optional direct forces."""
+
+    def __init__(self, emb_size: int, out_size: int, is_extensive: bool = True, regress_forces: bool = False,
+                 direct_forces: bool = True, activation: nn.Module = nn.SiLU(),
+                 weight_init: Callable[[Tensor], Tensor] | None = None):
+        super().__init__()
+        self.emb_size = emb_size
+        self.out_size = out_size
+        self.is_extensive = is_extensive
+        self.regress_forces = regress_forces
+        self.direct_forces = direct_forces
+        self.out_lin = nn.Sequential(
+            Dense(emb_size, emb_size, True, weight_init), activation,
+            Dense(emb_size, emb_size // 2, True, weight_init), activation,
+            Dense(emb_size // 2, out_size, False, weight_init),
+        )
+        if regress_forces and direct_forces:
+            self.out_lin_force = nn.Sequential(
+                Dense(2 * emb_size, emb_size, True, weight_init), activation,
+                Dense(emb_size, emb_size // 2, True, weight_init), activation,
+                Dense(emb_size // 2, 1, False, weight_init),
+            )
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, batch_idx: Tensor | None, idx_s: Tensor, idx_t: Tensor, edge_vec_st: Tensor,
+                pos: Tensor, n_graphs: int | None = None):
+        prop = run_mlp(self.out_lin, x)
+        if batch_idx is not None:
+            prop = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce="sum" if self.is_extensive else "mean")
+        else:
+            prop = prop.sum(0, keepdim=True) if self.is_extensive else prop.mean(0, keepdim=True)
+        if not self.regress_forces:
+            return prop
+        if self.direct_forces:
+            x = x.contiguous()
+            force_st = run_mlp(self.out_lin_force, torch.cat([x[idx_s], x[idx_t]], dim=-1)) * edge_vec_st
+            return prop, scatter(force_st, idx_s, dim=0, dim_size=x.size(0))
+        raise NotImplementedError(
+            "regress_forces with direct_forces=False needs -dE/dpos through the HIP kernels; their backward "
+            "pass is not built yet (SURVEY.md §8f-3)")
+
+
+class LCAONet(BaseMPNN):
+    """Drop-in for lcaonet.model.LCAONet (reference lcaonet.py:322-540).  Also accepts the README spellings
+    hidden_dim / coeffs_dim / conv_dim / out_dim."""
+
+    def __init__(self, emb_size: int = 128, emb_size_coeff: int = 128, emb_size_conv: int = 128, out_size: int = 1,
+                 n_interaction: int = 3, n_per_orb: int = 1, cutoff: float = 6.0,
+                 rbf_type: str | type[BaseRadialBasis] = "hydrogen", cutoff_net: str | type[BaseCutoff] = "envelope",
+                 max_z: int = 36, min_orb: str | None = None, max_orb: str | None = None, elec_to_node: bool = True,
+                 add_valence: bool = False, extend_orb: bool = False, is_extensive: bool = True,
+                 activation: str = "SiLU", weight_init: str | None = "glorotorthogonal",
+                 atomref: Tensor | None = None, mean: Tensor | None = None, regress_forces: bool = False,
+                 direct_forces: bool = True, hidden_dim: int | None = None, coeffs_dim: int | None = None,
+                 conv_dim: int | None = None, out_dim: int | None = None):
+        super().__init__()
+        emb_size = hidden_dim if hidden_dim is not None else emb_size
+        emb_size_coeff = coeffs_dim if coeffs_dim is not None else emb_size_coeff
+        emb_size_conv = conv_dim if conv_dim is not None else emb_size_conv
+        out_size = out_dim if out_dim is not None else out_size
+        wi = init_resolver(weight_init) if weight_init is not None else None
+        act = activation_resolver(activation)
+        self.emb_size = emb_size
+        self.emb_size_coeff = emb_size_coeff
+        self.emb_size_conv = emb_size_conv
+        self.out_size = out_size
+        self.n_interaction = n_interaction
+        self.cutoff = cutoff
+        self.cutoff_net = cutoff_net
+        self.elec_to_node = elec_to_node
+        self.add_valence = add_valence
+        self.regress_forces = regress_forces
+        self.direct_forces = direct_forces
+
+        elec_info = ElecInfo(max_z, max_orb, min_orb, n_per_orb)
+        self.elec_info = elec_info
+        cn = cutoffnet_resolver(cutoff_net, cutoff=cutoff)
+        self.rbf = rbf_resolver(rbf_type, cutoff=cutoff, elec_info=elec_info, cutoff_net=cn)
+        self.shbf = SphericalHarmonicsBasis(elec_info)
+        self.n_l = int(elec_info.nl_list[:, 1].max()) + 1
+
+        self.emb_layer = LCAOEmbedding(emb_size, emb_size_coeff, elec_info, max_z, elec_to_node, extend_orb, act, wi)
+        if add_valence:
+            self.valence_mask = ValenceMask(emb_size_conv, elec_info)
+        self.int_layers = nn.ModuleList(
+            [LCAOInteraction(emb_size, emb_size_coeff, emb_size_conv, add_valence, act, wi) for _ in range(n_interaction)])
+        self.out_layer = LCAOOut(emb_size, out_size, is_extensive, regress_forces, direct_forces, act, wi)
+        self.pp_layer = PostProcess(out_size, is_extensive, atomref, mean)
+
+    # --- index / geometry helpers with the reference's names -------------------------------------------
+    @torch.no_grad()
+    def get_triplets(self, graph):
+        """Materialise the reference's triplet lists (lcaonet.py:439-486) into the graph: for each edge
+        e=(s->t) in order, every edge e'=(k->s) ordered by k, except e itself.  The fused forward never needs
+        them (it walks the in-edge CSR instead); this exists for the operator-level API and for tests."""
+        idx_s, idx_t = graph[GraphKeys.Edge_idx]
+        N = graph[GraphKeys.Z].size(0)
+        E = idx_s.numel()
+        order = torch.argsort(idx_t * N + idx_s, stable=True)          # in-edges grouped by target, by source
+        ptr = torch.searchsorted(idx_t[order], torch.arange(N + 1, device=idx_s.device))
+        n_in = (ptr[1:] - ptr[:-1])[idx_s]
+        e_st = torch.repeat_interleave(torch.arange(E, device=idx_s.device), n_in)
+        start = torch.cumsum(n_in, 0) - n_in
+        offs = torch.arange(e_st.numel(), device=idx_s.device) - start[e_st]
+        e_ks = order[ptr[idx_s[e_st]] + offs]
+        keep = e_ks != e_st
+        e_ks, e_st = e_ks[keep], e_st[keep]
+        graph[GraphKeys.Idx_k_3b] = idx_s[e_ks]
+        graph[GraphKeys.Edge_idx_ks_3b] = e_ks
+        graph[GraphKeys.Edge_idx_st_3b] = e_st
+        return graph
+
+    @torch.no_grad()
+    def calc_3body_angles(self, graph):
+        vec = graph.get(GraphKeys.Edge_vec_st)
+        if vec is None:
+            raise ValueError("edge_vec_st is not calculated. Please run calc_atomic_distances(return_vec=True) first.")
+        graph[GraphKeys.Angles_3b] = ops.triplet_angles(vec, graph[GraphKeys.Edge_idx_st_3b],
+                                                        graph[GraphKeys.Edge_idx_ks_3b])
+        return graph
+
+    # --- forward ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
+                trace: dict | None = None):
+        """graph: PyG-Batch-like object with z, pos, edge_index [centre, neighbour], edge_shift, lattice and
+        optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
+        Inference only for now: no autograd graph is recorded (backward kernels: SURVEY.md §8f-3)."""
+        if self.regress_forces and not self.direct_forces:
+            raise NotImplementedError(
+                "regress_forces with direct_forces=False needs -dE/dpos through the HIP kernels; their backward "
+                "pass is not built yet (SURVEY.md §8f-3)")
+        batch_idx = graph.get(GraphKeys.Batch_idx)
+        z = graph[GraphKeys.Z]
+        pos = graph[GraphKeys.Pos]
+        edge_index = graph[GraphKeys.Edge_idx]
+        idx_s, idx_t = edge_index[0], edge_index[1]
+        ops._dev(pos, "graph.pos")
+        N = z.size(0)
+
+        ctx = EdgeContext.build(edge_index, N)
+        graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
+        dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
+        if materialize_triplets:
+            graph = self.calc_3body_angles(self.get_triplets(graph))
+
+        rb = self.rbf(dist)
+        if self.training:
+            x, cst = self.emb_layer(z, idx_s, idx_t)  # BatchNorm batch statistics: module path
+        else:
+            x, cst = self.emb_layer.forward_species(z, ctx)
+        valence_ed = self.valence_mask.per_edge(z, idx_t) if self.add_valence else None
+
+        if trace is not None:
+            trace.update(rb=rb, x0=x, cst=cst, order=ctx.order)
+        for i, inte in enumerate(self.int_layers):
+            tr = {} if trace is not None else None
+            x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr)
+            if trace is not None:
+                trace[f"x{i + 1}"] = x
+                trace[f"three_body_w{i + 1}"] = tr["three_body_w"]
+
+        n_graphs = None
+        if batch_idx is not None:
+            lat = graph.get(GraphKeys.Lattice)
+            n_graphs = lat.shape[0] if (lat is not None and lat.dim() == 3) else None  # avoids batch.max().item()
+        out = self.out_layer(x, batch_idx, idx_s, idx_t, uvec, pos, n_graphs)
+        return self.pp_layer(out, z, batch_idx, n_graphs)

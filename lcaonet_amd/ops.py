@@ -1,0 +1,276 @@
+"""Tensor-level wrappers over the C ABI (include/lcaonet_hip.h).  PyTorch is plumbing here: it owns the
+device buffers and the stream; every number is produced by liblcaonet_hip.so.  No CPU path exists."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
+CUTOFF_KINDS = {"envelope": 0, "polynomial": 1, "cosine": 2, "none": 3}
+RBF_KINDS = {"hydrogen": 0, "bessel": 1}
+ORB_STRIDE = 12
+FUSED_WIDTHS = (32, 64, 128)
+
+
+def _p(t: Tensor | None):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: Tensor, name: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise _lib.LcaoHipError(f"{name} is on {t.device}: lcaonet_amd runs on a ROCm GPU only (no CPU fallback)")
+
+
+def _f32(t: Tensor, name: str = "tensor") -> Tensor:
+    _dev(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64(t: Tensor, name: str = "index") -> Tensor:
+    _dev(t, name)
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i32(t: Tensor, name: str = "index") -> Tensor:
+    _dev(t, name)
+    if t.dtype != torch.int32:
+        raise TypeError(f"{name} must be int32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --- optional per-kernel timing (bench.py): HIP events on the launch stream around every C-ABI call ------
+_PROFILE: dict | None = None
+
+
+class profile:
+    """with ops.profile() as prof: ...  -> prof.summary() = {entry point: (calls, total ms)} after a sync."""
+
+    def __enter__(self):
+        global _PROFILE
+        self.events = {}
+        _PROFILE = self.events
+        return self
+
+    def __exit__(self, *exc):
+        global _PROFILE
+        _PROFILE = None
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+
+
+def _call(name: str, *args) -> None:
+    fn = getattr(_lib.load(), name)
+    if _PROFILE is None:
+        _lib.check(fn(*args), name)
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.check(fn(*args), name)
+    b.record()
+    _PROFILE.setdefault(name, []).append((a, b))
+
+
+def edge_geometry(pos, idx_s, idx_t, shift, lattice, batch):
+    pos, shift, lattice = _f32(pos, "pos"), _f32(shift, "edge_shift"), _f32(lattice, "lattice")
+    idx_s, idx_t = _i64(idx_s), _i64(idx_t)
+    batch = _i64(batch) if batch is not None else None
+    E = idx_s.numel()
+    dist = torch.empty(E, device=pos.device, dtype=torch.float32)
+    uvec = torch.empty(E, 3, device=pos.device, dtype=torch.float32)
+    _call("lcao_edge_geometry", _p(pos), _p(idx_s), _p(idx_t), _p(shift), _p(lattice), _p(batch), E, _p(dist),
+                                      _p(uvec), _stream())
+    return dist, uvec
+
+
+def cutoff(r: Tensor, kind: str, rc: float) -> Tensor:
+    r = _f32(r, "r")
+    out = torch.empty_like(r)
+    _call("lcao_cutoff", _p(r), r.numel(), CUTOFF_KINDS[kind], float(rc), _p(out), _stream())
+    return out
+
+
+def radial_basis(r: Tensor, orb_table: Tensor, rbf_kind: str, cutoff_kind: str, rc: float) -> Tensor:
+    r = _f32(r, "r")
+    orb_table = _f32(orb_table, "orb_table")
+    D = orb_table.shape[0]
+    rb = torch.empty(r.numel(), D, device=r.device, dtype=torch.float32)
+    _call("lcao_radial_basis", _p(r), r.numel(), D, _p(orb_table), RBF_KINDS[rbf_kind],
+                                     CUTOFF_KINDS[cutoff_kind], float(rc), _p(rb), _stream())
+    return rb
+
+
+def sph_basis(costheta: Tensor, l_of_d: Tensor) -> Tensor:
+    c = _f32(costheta, "costheta")
+    l_of_d = _i32(l_of_d, "l_of_d")
+    D = l_of_d.numel()
+    out = torch.empty(c.numel(), D, device=c.device, dtype=torch.float32)
+    _call("lcao_sph_basis", _p(c), c.numel(), D, _p(l_of_d), _p(out), _stream())
+    return out
+
+
+def triplet_angles(uvec: Tensor, e_st: Tensor, e_ks: Tensor) -> Tensor:
+    uvec, e_st, e_ks = _f32(uvec), _i64(e_st), _i64(e_ks)
+    out = torch.empty(e_st.numel(), device=uvec.device, dtype=torch.float32)
+    _call("lcao_triplet_angles", _p(uvec), _p(e_st), _p(e_ks), e_st.numel(), _p(out), _stream())
+    return out
+
+
+def dense(x: Tensor, weight: Tensor, bias: Tensor | None = None, act: int = ACT_NONE,
+          residual: Tensor | None = None) -> Tensor:
+    """act(x @ weight.T + bias) + residual on the last dim of x (any leading dims)."""
+    x = _f32(x, "x")
+    weight = _f32(weight, "weight")
+    N, K = weight.shape
+    if x.shape[-1] != K:
+        raise ValueError(f"dense: x has {x.shape[-1]} features, weight expects {K}")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K)
+    M = x2.shape[0]
+    bias = _f32(bias, "bias") if bias is not None else None
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    r2 = None
+    if residual is not None:
+        r2 = _f32(residual, "residual").reshape(M, N)
+    _call("lcao_dense", _p(x2), K, _p(weight), _p(bias), _p(r2), N, _p(y), N, M, K, N, act, _stream())
+    return y.reshape(*lead, N)
+
+
+def segment_sum(a: Tensor, ptr: Tensor, b: Tensor | None = None) -> Tensor:
+    a = _f32(a, "a")
+    ptr = _i32(ptr, "ptr")
+    n_seg = ptr.numel() - 1
+    width = a.shape[1] if a.dim() > 1 else 1
+    b = _f32(b, "b") if b is not None else None
+    out = torch.empty((n_seg, width), device=a.device, dtype=torch.float32)
+    _call("lcao_segment_sum", _p(a), _p(b), _p(ptr), n_seg, width, _p(out), _stream())
+    return out
+
+
+def gather_rows(table: Tensor, idx: Tensor) -> Tensor:
+    table = _f32(table, "table")
+    width = int(table[0].numel()) if table.shape[0] > 0 else int(torch.tensor(table.shape[1:]).prod())
+    out = torch.empty((idx.numel(),) + tuple(table.shape[1:]), device=table.device, dtype=torch.float32)
+    if idx.dtype == torch.int32:
+        idx = _i32(idx)
+        _call("lcao_permute_rows", _p(table), _p(idx), idx.numel(), width, _p(out), _stream())
+    else:
+        idx = _i64(idx)
+        _call("lcao_gather_rows", _p(table), _p(idx), idx.numel(), width, _p(out), _stream())
+    return out
+
+
+def _mask_args(mask: Tensor | None):
+    if mask is None:
+        return None, 0, 0, 0
+    _dev(mask, "valence_mask")
+    if mask.dtype != torch.float32:
+        mask = mask.float()
+    if mask.dim() == 2:
+        return mask, mask.stride(0), mask.stride(1), 0
+    return mask, mask.stride(0), mask.stride(1), mask.stride(2)
+
+
+def coeff_contract(cstf, rb, order, l_of_d, mask, V, n_l, valence):
+    cstf, rb = _f32(cstf, "cstf"), _f32(rb, "rb")
+    E, D = rb.shape
+    mask, mse, msd, msv = _mask_args(mask if valence else None)
+    A = torch.empty(E, n_l, V, device=rb.device, dtype=torch.float32)
+    B = torch.empty(E, V, device=rb.device, dtype=torch.float32)
+    Bv = torch.empty(E, V, device=rb.device, dtype=torch.float32) if valence else None
+    _call("lcao_coeff_contract", _p(cstf), _p(rb), _p(order), _p(l_of_d), _p(mask), mse, msd, msv, E, D, V, n_l,
+                                       int(valence), _p(A), _p(B), _p(Bv), _stream())
+    return A, B, Bv
+
+
+def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence):
+    cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
+    E, D = rb.shape
+    V, C = W1.shape
+    valence_ed = _f32(valence_ed) if valence else None
+    A = torch.empty(E, n_l, V, device=rb.device, dtype=torch.float32)
+    B = torch.empty(E, V, device=rb.device, dtype=torch.float32)
+    Bv = torch.empty(E, V, device=rb.device, dtype=torch.float32) if valence else None
+    _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(order), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2), E, D,
+                                           C, V, n_l, int(valence), _p(A), _p(B), _p(Bv), _stream())
+    return A, B, Bv
+
+
+def triplet_sum(A, gate, uvec, order, src_p, in_ptr, in_pos):
+    A, gate, uvec = _f32(A), _f32(gate), _f32(uvec)
+    E, n_l, V = A.shape
+    tbw = torch.empty(E, V, device=A.device, dtype=torch.float32)
+    _call("lcao_triplet_sum", _p(A), _p(gate), _p(uvec), _p(order), _p(src_p), _p(in_ptr), _p(in_pos), E, V, n_l,
+                                    _p(tbw), _stream())
+    return tbw
+
+
+def edge_combine(ft, B, Bv):
+    ft, B = _f32(ft), _f32(B)
+    E, V = B.shape
+    lw = torch.empty(E, V, device=B.device, dtype=torch.float32)
+    _call("lcao_edge_combine", _p(ft), _p(B), _p(Bv), E, V, _p(lw), _stream())
+    return lw
+
+
+def pair_silu(Ps, Pt, src_p, dst_p):
+    Ps, Pt = _f32(Ps), _f32(Pt)
+    E, V = src_p.numel(), Ps.shape[1]
+    h1 = torch.empty(E, V, device=Ps.device, dtype=torch.float32)
+    _call("lcao_pair_silu", _p(Ps), _p(Pt), _p(src_p), _p(dst_p), E, V, _p(h1), _stream())
+    return h1
+
+
+def embed_coeffs(FE, U, Vt, scale, shift, z, src_p, dst_p):
+    FE, U, Vt, scale, shift = _f32(FE), _f32(U), _f32(Vt), _f32(scale), _f32(shift)
+    z = _i64(z)
+    _, D, C = FE.shape
+    E = src_p.numel()
+    cst = torch.empty(E, D, C, device=FE.device, dtype=torch.float32)
+    _call("lcao_embed_coeffs", _p(FE), _p(U), _p(Vt), _p(scale), _p(shift), _p(z), _p(src_p), _p(dst_p), E, D, C,
+                                     _p(cst), _stream())
+    return cst
+
+
+def triplet_literal(cstf, rb, shb, xk, tri_k, e_ks, mask, V, valence):
+    cstf, rb, shb = _f32(cstf), _f32(rb), _f32(shb)
+    _dev(xk)
+    if xk.stride(-1) != 1:
+        xk = xk.contiguous()
+    T, D = shb.shape
+    tri_k, e_ks = _i64(tri_k), _i64(e_ks)
+    mask, mse, msd, msv = _mask_args(mask if valence else None)
+    w = torch.empty(T, V, device=rb.device, dtype=torch.float32)
+    _call("lcao_triplet_literal", _p(cstf), _p(rb), _p(shb), _p(xk), xk.stride(0), _p(tri_k), _p(e_ks), _p(mask),
+                                        mse, msd, msv, T, D, V, int(valence), _p(w), _stream())
+    return w
+
+
+def edge_lcao_weight(tbw, B, W3, Wb):
+    tbw, B, W3, Wb = _f32(tbw), _f32(B), _f32(W3), _f32(Wb)
+    E, V = B.shape
+    bw = torch.empty(E, V, device=B.device, dtype=torch.float32)
+    _call("lcao_edge_lcao_weight", _p(tbw), _p(B), _p(W3), _p(Wb), E, V, _p(bw), _stream())
+    return bw
+
+
+def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2):
+    bw, Ps, Pt, Wn2, bn2 = _f32(bw), _f32(Ps), _f32(Pt), _f32(Wn2), _f32(bn2)
+    E, V = bw.shape
+    msg = torch.empty(E, V, device=bw.device, dtype=torch.float32)
+    _call("lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg),
+                                          _stream())
+    return msg

@@ -1,0 +1,80 @@
+"""String / type -> object resolvers: same names, normalisation and errors as the reference's
+lcaonet/utils/resolve.py:16-147 (the only plugin mechanism the reference has: a user may hand
+`LCAONet` a BaseRadialBasis / BaseCutoff subclass instead of a name)."""
+from __future__ import annotations
+
+from collections.abc import Callable
+from inspect import getmembers, isfunction
+from typing import Any
+
+import torch
+
+from .inits import glorot, glorot_orthogonal
+
+
+def _normalize_string(s: str) -> str:
+    return s.lower().replace("-", "").replace("_", "").replace(" ", "")
+
+
+def _resolver(query: Any, classes: list, base_cls: type | None = None, return_initialize: bool = True, **kwargs):
+    if isinstance(query, str):
+        for cls in classes:
+            if _normalize_string(cls.__name__.lower()) == query:
+                return cls(**kwargs) if return_initialize else cls
+    elif isinstance(query, type):
+        if query in classes or (base_cls is not None and issubclass(query, base_cls)):
+            return query(**kwargs) if return_initialize else query
+    elif callable(query):
+        if query in classes:
+            return query
+    else:
+        raise ValueError(f"{query} must be str or type or class")
+    raise ValueError(f"{query} not found")
+
+
+def _activation_classes() -> list:
+    from ..nn.activation import ShiftedSoftplus, Swish
+
+    acts = [a for a in vars(torch.nn.modules.activation).values()
+            if isinstance(a, type) and issubclass(a, torch.nn.Module)]
+    return acts + [Swish, ShiftedSoftplus]
+
+
+def activation_resolver(query: torch.nn.Module | str = "relu", **kwargs) -> torch.nn.Module:
+    if isinstance(query, str):
+        query = _normalize_string(query)
+    return _resolver(query, _activation_classes(), torch.nn.Module, **kwargs)
+
+
+def init_resolver(query: Callable | str = "orthogonal") -> Callable:
+    if isinstance(query, str):
+        query = _normalize_string(query)
+    funcs = [f[1] for f in getmembers(torch.nn.init, isfunction)] + [glorot, glorot_orthogonal]
+    funcs = [f for f in funcs if "deprecated" not in str(f)]
+    return _resolver(query, funcs, return_initialize=False)
+
+
+def init_param_resolver(query: Callable) -> tuple[str, ...]:
+    return query.__code__.co_varnames[: query.__code__.co_argcount]
+
+
+def cutoffnet_resolver(query="polynomialcutoff", **kwargs):
+    from ..nn import cutoff as C
+
+    if isinstance(query, str):
+        query = _normalize_string(query)
+        if query[-6:] != "cutoff":
+            query += "cutoff"
+    cns = [c for c in vars(C).values() if isinstance(c, type) and issubclass(c, C.BaseCutoff)]
+    return _resolver(query, cns, C.BaseCutoff, True, **kwargs)
+
+
+def rbf_resolver(query="hydrogenradialbasis", **kwargs):
+    from ..nn import rbf as R
+
+    if isinstance(query, str):
+        query = _normalize_string(query)
+        if query[-11:] != "radialbasis":
+            query += "radialbasis"
+    rbfs = [c for c in vars(R).values() if isinstance(c, type) and issubclass(c, R.BaseRadialBasis)]
+    return _resolver(query, rbfs, R.BaseRadialBasis, True, **kwargs)
