@@ -127,11 +127,21 @@ int lcao_triplet_literal(const float* cstf, const float* rb, const float* shb, c
 
 /* lcaonet.py:170 + the contraction above in ONE kernel: f_coeffs = SiLU(SiLU(cst W1^T) W2^T) is never
  * written to HBM.  cst (E, D, C) orig order; W1 (V, C); W2 (Vt, V).  fp32 MFMA (v_mfma_f32_16x16x4_f32).
- * gate/src_p nullable: when given, also writes Ag[p,l,:] = A[p,l,:] * gate[src_p[p],:] (may be NULL). */
+ * Outputs (p-space): B (E,V) [, Bv (E,V) with valence];  and EITHER the raw A (E,n_l,V) (Ag == NULL)
+ * OR, for lcao_triplet_gemm, the gated copy Ag[p,l,:] = A[p,l,:] * gate[src_p[p],:] plus the per-edge Gram
+ * matrix gram[p, 10] (upper triangle of A A^T over l, l' <= 3, row-major; ungated).  A is scratch when valence. */
 int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
                             const float* valence_ed /* (E,D) orig order, nullable */, const float* W1,
-                            const float* W2, int64_t n_edges, int n_orb, int C, int V, int n_l, int valence,
-                            float* A, float* B, float* Bv, void* stream);
+                            const float* W2, const float* gate /* (N,V) sigmoid(xk), nullable */,
+                            const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, int valence,
+                            float* A, float* B, float* Bv, float* Ag, float* gram, void* stream);
+
+/* lcaonet.py:173-189 as one small fp32-MFMA GEMM per centre node (no LDS, no T-sized tensor):
+ *   tbw[p,:] = sum_{q in In(s), q != p}  sum_l  Y_l(u_p.u_q) / max(sqrt(Y^T G_q Y), 1e-12) * Ag[q,l,:]
+ * Ag / gram from lcao_coeff_mlp_contract; uvec_p (E,3) unit vectors in p-space; CSR as lcao_triplet_sum. */
+int lcao_triplet_gemm(const float* Ag, const float* gram, const float* uvec_p, const int32_t* in_ptr,
+                      const int32_t* in_pos, const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int V, int n_l,
+                      float* tbw, void* stream);
 
 /* lcaonet.py:192-204 + basis_weight (:209) in ONE kernel (no valence):
  *   bw[p,:] = normalize( (1 + tbw[p,:] W3^T) * B[p,:] ) Wb^T          W3, Wb (V, V) */

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
                                                    const float* __restrict__ wmul /* (E,D) or null */,
                                                    const float* __restrict__ W1, const float* __restrict__ W2,
                                                    int64_t E, int D, int accumulate, float* __restrict__ A,
-                                                   float* __restrict__ Bout) {
+                                                   float* __restrict__ Bout, const float* __restrict__ gate,
+                                                   const int32_t* __restrict__ src_p, float* __restrict__ Ag,
+                                                   float* __restrict__ gram) {
   constexpr int KT1 = C / 16, MT = V / 16;
   extern __shared__ float lds[];
   float* w1s = lds;
@@ -268,20 +270,65 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
         }
       }
     }
+    // Bout of a pass is the sum over l of THIS pass' accumulators (B in pass 1, Bv in the valence pass)
+    f32x4v bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      bsum[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int l = 0; l < NL; ++l) bsum[m] += acc[l][m];
+    }
+    if (accumulate) {  // valence pass: add the first pass' A (written ungated) before finalising
+      const float* Ain = A + pc * (int64_t)NL * V + 4 * q;
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[l][m] += *(const f32x4v*)(Ain + l * V + 16 * m);
+    }
+    if (gram) {
+      // Gram matrix of the (ungated) per-l vectors: in-lane partial over this lane's 4*MT features, then the
+      // four quarters of the edge are summed with two cross-lane steps.  G[l][l'] feeds the per-triplet norm.
+      float g[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) g[i] = 0.f;
+      int gi = 0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int l2 = l; l2 < 4; ++l2) {
+          if (l < NL && l2 < NL) {
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) t += acc[l][m][j] * acc[l2][m][j];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            g[gi] = t;
+          }
+          ++gi;
+        }
+      if (valid && q == 0) {
+        float* gp = gram + p * 10;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) gp[i] = g[i];
+      }
+    }
     if (valid) {
       float* Ap = A + p * (int64_t)NL * V + 4 * q;
       float* Bp = Bout + p * (int64_t)V + 4 * q;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        f32x4v bsum = f32x4v{0.f, 0.f, 0.f, 0.f};
+        *(f32x4v*)(Bp + 16 * m) = bsum[m];
+        if (Ag) {
+          const f32x4v gt = *(const f32x4v*)(gate + (int64_t)src_p[p] * V + 16 * m + 4 * q);
+          float* Agp = Ag + p * (int64_t)NL * V + 4 * q;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-          bsum += acc[l][m];
-          f32x4v v = acc[l][m];
-          if (accumulate) v += *(const f32x4v*)(Ap + l * V + 16 * m);
-          *(f32x4v*)(Ap + l * V + 16 * m) = v;
+          for (int l = 0; l < NL; ++l) *(f32x4v*)(Agp + l * V + 16 * m) = acc[l][m] * gt;
+        } else {
+#pragma unroll
+          for (int l = 0; l < NL; ++l) *(f32x4v*)(Ap + l * V + 16 * m) = acc[l][m];
         }
-        *(f32x4v*)(Bp + 16 * m) = bsum;
       }
     }
   }
@@ -290,7 +337,8 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
 template <int C, int V, int NL>
 static int launch_coeff_mlp(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
                             const float* wmul, const float* W1, const float* W2, int64_t E, int D, int accumulate,
-                            float* A, float* Bout, hipStream_t st) {
+                            float* A, float* Bout, const float* gate, const int32_t* src_p, float* Ag, float* gram,
+                            hipStream_t st) {
   size_t lds = (size_t(V) * (C + 4) + size_t(V) * (V + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -305,19 +353,21 @@ static int launch_coeff_mlp(const float* cst, const float* rb, const int32_t* or
   int64_t cap = (int64_t)lcao_num_cu() * per_cu;
   if (groups > cap) groups = cap;
   hipLaunchKernelGGL((k_coeff_mlp<C, V, NL>), dim3((unsigned)groups), dim3(256), lds, st, cst, rb, order, l_of_d,
-                     wmul, W1, W2, E, D, accumulate, A, Bout);
+                     wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram);
   return lcao_launch_status();
 }
 
 template <int C, int V>
 static int dispatch_coeff_mlp_nl(int n_l, const float* cst, const float* rb, const int32_t* order,
                                  const int32_t* l_of_d, const float* wmul, const float* W1, const float* W2,
-                                 int64_t E, int D, int accumulate, float* A, float* Bout, hipStream_t st) {
+                                 int64_t E, int D, int accumulate, float* A, float* Bout, const float* gate,
+                                 const int32_t* src_p, float* Ag, float* gram, hipStream_t st) {
+#define CM_NL(NL_) \
+  case NL_:        \
+    return launch_coeff_mlp<C, V, NL_>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, st)
   switch (n_l) {
-    case 1: return launch_coeff_mlp<C, V, 1>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, st);
-    case 2: return launch_coeff_mlp<C, V, 2>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, st);
-    case 3: return launch_coeff_mlp<C, V, 3>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, st);
-    case 4: return launch_coeff_mlp<C, V, 4>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, st);
+    CM_NL(1); CM_NL(2); CM_NL(3); CM_NL(4);
+#undef CM_NL
     default: return LCAO_ERR_INVALID;
   }
 }
@@ -329,23 +379,30 @@ extern "C" size_t lcao_lds_bytes_coeff_mlp(int C, int V, int valence) {
 
 extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* order,
                                        const int32_t* l_of_d, const float* valence_ed, const float* W1,
-                                       const float* W2, int64_t n_edges, int n_orb, int C, int V, int n_l,
-                                       int valence, float* A, float* B, float* Bv, void* stream) {
+                                       const float* W2, const float* gate, const int32_t* src_p, int64_t n_edges,
+                                       int n_orb, int C, int V, int n_l, int valence, float* A, float* B, float* Bv,
+                                       float* Ag, float* gram, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   if (n_orb <= 0 || C <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
   LCAO_CHECK_PTR(cst); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(W1); LCAO_CHECK_PTR(W2);
-  LCAO_CHECK_PTR(A); LCAO_CHECK_PTR(B);
-  if (valence) { LCAO_CHECK_PTR(valence_ed); LCAO_CHECK_PTR(Bv); }
+  LCAO_CHECK_PTR(B);
+  if (valence) { LCAO_CHECK_PTR(valence_ed); LCAO_CHECK_PTR(Bv); LCAO_CHECK_PTR(A); }
+  if (Ag) { LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(gram); } else { LCAO_CHECK_PTR(A); }
   hipStream_t st = (hipStream_t)stream;
   int rc = LCAO_ERR_UNSUPPORTED;
-#define CM_CASE(C_, V_)                                                                                          \
-  if (C == C_ && V == V_) {                                                                                      \
-    rc = dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, B, st); \
-    if (rc == LCAO_OK && valence)                                                                                \
-      rc = dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, valence_ed, W1, W2 + (size_t)V_ * V_,       \
-                                         n_edges, n_orb, 1, A, Bv, st);                                          \
-    return rc;                                                                                                   \
+  // no valence: one pass, finalised (gated + Gram) directly.  valence: pass 1 writes the raw A of the plain half
+  // [c], pass 2 runs the [cv] half of W2 with rb * valence as the orbital weight, adds pass 1's A and finalises.
+#define CM_CASE(C_, V_)                                                                                            \
+  if (C == C_ && V == V_) {                                                                                        \
+    if (!valence)                                                                                                  \
+      return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, B,  \
+                                           gate, src_p, Ag, Ag ? gram : nullptr, st);                              \
+    rc = dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, B,      \
+                                       nullptr, nullptr, nullptr, nullptr, st);                                    \
+    if (rc != LCAO_OK) return rc;                                                                                  \
+    return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, valence_ed, W1, W2 + (size_t)V_ * V_,        \
+                                         n_edges, n_orb, 1, A, Bv, gate, src_p, Ag, Ag ? gram : nullptr, st);      \
   }
   CM_CASE(128, 128)
   CM_CASE(64, 64)
@@ -524,5 +581,162 @@ extern "C" int lcao_edge_node_message(const float* bw, const float* Ps, const fl
   }
   NM_CASE(128) NM_CASE(64) NM_CASE(32)
 #undef NM_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}
+
+// ===================================================================================================
+// lcao_triplet_gemm — the three-body term (lcaonet.py:173-189) as one small GEMM per centre node s:
+//
+//     tbw[Out(s), :] = W_s . Ag[In(s), :, :]        W_s[p, (q,l)] = Y_l(u_p . u_q) / max(|v_pq|, 1e-12)   (q != p)
+//
+// Ag[q,l,:] = A[q,l,:] * sigmoid(xk)[src(q),:] is written by lcao_coeff_mlp_contract; the per-triplet norm
+// |v_pq|^2 = |sum_l Y_l A[q,l,:]|^2 = sum_{l,l'} Y_l Y_l' G_q[l,l'] comes from the per-edge Gram matrix G_q of
+// the ungated A (10 floats), so no per-triplet V-long reduction and no T-sized tensor exist.
+// One wave per node; the 16-B row pieces of Ag are the MFMA "A" operand straight from global memory (coalesced
+// 256-B segments, every row of Ag is read exactly once in the whole launch), W is built per lane from wave-uniform
+// scalars (u_q, G_q) and the lane's own out-edge direction and is the "B" operand.  No LDS.
+//   k-step = one in-edge q (quarter = l; l >= n_l contributes zero), 32 out-edges per pass (two 16-wide tiles).
+//   accumulator tile (h, jj), lane (n, quarter), reg r  <->  out-edge n, channel 64h + 16*quarter + 4r + jj.
+//   HBM per edge: read 4*n_l*V + 40 + 12; write 4*V.
+// ===================================================================================================
+__device__ __forceinline__ int gram_idx(int l, int l2) {  // l <= l2, row-major upper triangle of a 4x4
+  return l * 4 - (l * (l - 1)) / 2 + (l2 - l);
+}
+
+template <int NL>
+__device__ __forceinline__ float triplet_weight(float ux, float uy, float uz, float qx, float qy, float qz,
+                                                const float (&G)[10], int quarter, bool ok) {
+  const float c = ux * qx + uy * qy + uz * qz;
+  float y[4];
+  y[0] = lcao_y_l0(c, 0);
+  y[1] = lcao_y_l0(c, 1);
+  y[2] = lcao_y_l0(c, 2);
+  y[3] = lcao_y_l0(c, 3);
+  float n2 = 0.f;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    n2 += y[l] * y[l] * G[gram_idx(l, l)];
+#pragma unroll
+    for (int l2 = l + 1; l2 < NL; ++l2) n2 += 2.0f * (y[l] * y[l2]) * G[gram_idx(l, l2)];
+  }
+  const float inv = 1.0f / fmaxf(sqrtf(fmaxf(n2, 0.f)), 1e-12f);
+  const float yq = quarter == 0 ? y[0] : (quarter == 1 ? y[1] : (quarter == 2 ? y[2] : y[3]));
+  return ok ? yq * inv : 0.f;
+}
+
+template <int V, int NL>
+__global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ Ag, const float* __restrict__ gram,
+                                                      const float* __restrict__ uvec_p,
+                                                      const int32_t* __restrict__ in_ptr,
+                                                      const int32_t* __restrict__ in_pos,
+                                                      const int32_t* __restrict__ out_ptr, int n_nodes,
+                                                      float* __restrict__ tbw) {
+  constexpr int HG = (V + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, quarter = lane >> 4;
+  const bool frag_ok0 = quarter < NL;
+  for (int s = blockIdx.x * 4 + wave; s < n_nodes; s += gridDim.x * 4) {
+    const int p0 = out_ptr[s], p1 = out_ptr[s + 1];
+    const int j0 = in_ptr[s], j1 = in_ptr[s + 1];
+    for (int pb = p0; pb < p1; pb += 32) {
+      const int pA = pb + n, pB = pb + 16 + n;
+      const bool vA = pA < p1, vB = pB < p1;
+      const bool two = (p1 - pb) > 16;  // wave-uniform
+      const float* ua = uvec_p + 3 * (int64_t)(vA ? pA : p0);
+      const float* ub = uvec_p + 3 * (int64_t)(vB ? pB : p0);
+      const float uax = ua[0], uay = ua[1], uaz = ua[2];
+      const float ubx = ub[0], uby = ub[1], ubz = ub[2];
+      f32x4v acc[2][HG][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < HG; ++h)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[t][h][jj] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+      // software pipeline: the A fragments of in-edge j+1 are in flight while in-edge j is multiplied
+      f32x4v cur[HG], nxt[HG];
+      int qe = (j0 < j1) ? in_pos[j0] : 0;
+#pragma unroll
+      for (int h = 0; h < HG; ++h) {
+        cur[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (j0 < j1 && frag_ok0 && (64 * h + 4 * n) < V)
+          cur[h] = *(const f32x4v*)(Ag + ((int64_t)qe * NL + quarter) * V + 64 * h + 4 * n);
+      }
+      for (int j = j0; j < j1; ++j) {
+        const int qn = (j + 1 < j1) ? in_pos[j + 1] : qe;
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+          nxt[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
+          if (j + 1 < j1 && frag_ok0 && (64 * h + 4 * n) < V)
+            nxt[h] = *(const f32x4v*)(Ag + ((int64_t)qn * NL + quarter) * V + 64 * h + 4 * n);
+        }
+        const float* uq = uvec_p + 3 * (int64_t)qe;
+        const float qx = uq[0], qy = uq[1], qz = uq[2];
+        float G[10];
+        const float* gp = gram + (int64_t)qe * 10;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) G[i] = gp[i];
+        // lcaonet.py:470 drops only the triplet whose two edges coincide (q == p); the back-triplet stays
+        const float wA = triplet_weight<NL>(uax, uay, uaz, qx, qy, qz, G, quarter, vA && qe != pA);
+#pragma unroll
+        for (int h = 0; h < HG; ++h)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[0][h][jj] = MFMA16(cur[h][jj], wA, acc[0][h][jj]);
+        if (two) {
+          const float wB = triplet_weight<NL>(ubx, uby, ubz, qx, qy, qz, G, quarter, vB && qe != pB);
+#pragma unroll
+          for (int h = 0; h < HG; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[1][h][jj] = MFMA16(cur[h][jj], wB, acc[1][h][jj]);
+        }
+#pragma unroll
+        for (int h = 0; h < HG; ++h) cur[h] = nxt[h];
+        qe = qn;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int p = t == 0 ? pA : pB;
+        if (t == 0 ? vA : vB) {
+#pragma unroll
+          for (int h = 0; h < HG; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ch = 64 * h + 16 * quarter + 4 * r;
+              if (ch < V) {
+                f32x4v v = {acc[t][h][0][r], acc[t][h][1][r], acc[t][h][2][r], acc[t][h][3][r]};
+                *(f32x4v*)(tbw + (int64_t)p * V + ch) = v;
+              }
+            }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int lcao_triplet_gemm(const float* Ag, const float* gram, const float* uvec_p, const int32_t* in_ptr,
+                                 const int32_t* in_pos, const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int V,
+                                 int n_l, float* tbw, void* stream) {
+  LCAO_CHECK_SIZE(n_nodes);
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
+  if (n_edges == 0 || n_nodes == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(Ag); LCAO_CHECK_PTR(gram); LCAO_CHECK_PTR(uvec_p); LCAO_CHECK_PTR(in_ptr); LCAO_CHECK_PTR(in_pos);
+  LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbw);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t groups = (n_nodes + 3) / 4;
+  int64_t cap = (int64_t)lcao_num_cu() * 8;
+  if (groups > cap) groups = cap;
+#define TG_CASE(V_, NL_)                                                                                          \
+  if (V == V_ && n_l == NL_) {                                                                                    \
+    hipLaunchKernelGGL((k_triplet_gemm<V_, NL_>), dim3((unsigned)groups), dim3(256), 0, st, Ag, gram, uvec_p, in_ptr, \
+                       in_pos, out_ptr, (int)n_nodes, tbw);                                                       \
+    return lcao_launch_status();                                                                                  \
+  }
+#define TG_V(V_) TG_CASE(V_, 1) TG_CASE(V_, 2) TG_CASE(V_, 3) TG_CASE(V_, 4)
+  TG_V(128) TG_V(64) TG_V(32)
+#undef TG_V
+#undef TG_CASE
   return LCAO_ERR_UNSUPPORTED;
 }

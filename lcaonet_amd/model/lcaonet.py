@@ -57,6 +57,13 @@ class EdgeContext:
     in_pos: Tensor     # (E)   p-indices of edges k->s grouped by s, ordered by (k, orig id)
     src_o: Tensor      # (E)   idx_s as int32, orig order
     dst_o: Tensor      # (E)   idx_t as int32, orig order
+    _uvec_p: Tensor | None = None
+
+    def uvec_p(self, uvec: Tensor) -> Tensor:
+        """Unit vectors permuted to p-space (computed once per forward, shared by the layers)."""
+        if self._uvec_p is None:
+            self._uvec_p = ops.gather_rows(uvec, self.order)
+        return self._uvec_p
 
     @staticmethod
     def build(edge_index: Tensor, n_nodes: int) -> "EdgeContext":
@@ -197,7 +204,7 @@ class LCAOInteraction(nn.Module):
     @torch.no_grad()
     def forward_fused(self, x: Tensor, cst: Tensor, valence_ed: Tensor | None, rb: Tensor, uvec: Tensor,
                       ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
-                      trace: dict | None = None) -> Tensor:
+                      trace: dict | None = None, exact_norm: bool = False) -> Tensor:
         """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1."""
         V = self.emb_size_conv
         if fused is None:
@@ -208,15 +215,20 @@ class LCAOInteraction(nn.Module):
         w1 = self.f_node[0].weight.detach()
         Ps = ops.dense(xs, w1[:, :V].contiguous(), self.f_node[0].bias.detach())
         Pt = ops.dense(xs, w1[:, V:].contiguous())
-        # coefficient MLP + radial contraction
+        # coefficient MLP + radial contraction, then the three-body term
         if fused:
-            A, B, Bv = ops.coeff_mlp_contract(cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
-                                              self.f_coeffs[2].weight.detach(), n_l, self.add_valence)
+            Ag, gram, B, Bv = ops.coeff_mlp_contract(
+                cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
+                self.f_coeffs[2].weight.detach(), n_l, self.add_valence,
+                gate=None if exact_norm else gate, src_p=ctx.src_p)
+            if exact_norm:   # per-triplet V-long norm (validation of the Gram-matrix form)
+                tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, ctx.in_ptr, ctx.in_pos)
+            else:
+                tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
         else:
             cstf = run_mlp(self.f_coeffs, cst)
             A, B, Bv = ops.coeff_contract(cstf, rb, ctx.order, l_of_d, valence_ed, V, n_l, self.add_valence)
-        # three-body term
-        tbw = ops.triplet_sum(A, gate, uvec, ctx.order, ctx.src_p, ctx.in_ptr, ctx.in_pos)
+            tbw = ops.triplet_sum(A, gate, uvec, ctx.order, ctx.src_p, ctx.in_ptr, ctx.in_pos)
         if trace is not None:
             trace["three_body_w"] = tbw  # p-space
         # two-body term and messages
@@ -365,7 +377,7 @@ class LCAONet(BaseMPNN):
     # --- forward ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
-                trace: dict | None = None):
+                trace: dict | None = None, exact_norm: bool = False):
         """graph: PyG-Batch-like object with z, pos, edge_index [centre, neighbour], edge_shift, lattice and
         optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
         Inference only for now: no autograd graph is recorded (backward kernels: SURVEY.md §8f-3)."""
@@ -398,7 +410,7 @@ class LCAONet(BaseMPNN):
             trace.update(rb=rb, x0=x, cst=cst, order=ctx.order)
         for i, inte in enumerate(self.int_layers):
             tr = {} if trace is not None else None
-            x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr)
+            x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr, exact_norm)
             if trace is not None:
                 trace[f"x{i + 1}"] = x
                 trace[f"three_body_w{i + 1}"] = tr["three_body_w"]

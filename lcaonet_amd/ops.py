@@ -196,17 +196,35 @@ def coeff_contract(cstf, rb, order, l_of_d, mask, V, n_l, valence):
     return A, B, Bv
 
 
-def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence):
+def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence, gate=None, src_p=None):
+    """Fused f_coeffs + radial contraction.  With `gate` (N,V) and `src_p`: returns (Ag, gram, B, Bv) for
+    triplet_gemm; without: (A, None, B, Bv) for the exact-norm triplet_sum."""
     cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
     E, D = rb.shape
     V, C = W1.shape
+    dev = rb.device
     valence_ed = _f32(valence_ed) if valence else None
-    A = torch.empty(E, n_l, V, device=rb.device, dtype=torch.float32)
-    B = torch.empty(E, V, device=rb.device, dtype=torch.float32)
-    Bv = torch.empty(E, V, device=rb.device, dtype=torch.float32) if valence else None
-    _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(order), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2), E, D,
-                                           C, V, n_l, int(valence), _p(A), _p(B), _p(Bv), _stream())
-    return A, B, Bv
+    B = torch.empty(E, V, device=dev, dtype=torch.float32)
+    Bv = torch.empty(E, V, device=dev, dtype=torch.float32) if valence else None
+    gated = gate is not None
+    A = torch.empty(E, n_l, V, device=dev, dtype=torch.float32) if (valence or not gated) else None
+    Ag = torch.empty(E, n_l, V, device=dev, dtype=torch.float32) if gated else None
+    gram = torch.empty(E, 10, device=dev, dtype=torch.float32) if gated else None
+    if gated:
+        gate = _f32(gate, "gate")
+    _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(order), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2), _p(gate),
+          _p(src_p), E, D, C, V, n_l, int(valence), _p(A), _p(B), _p(Bv), _p(Ag), _p(gram), _stream())
+    return (Ag if gated else A), gram, B, Bv
+
+
+def triplet_gemm(Ag, gram, uvec_p, in_ptr, in_pos, out_ptr):
+    Ag, gram, uvec_p = _f32(Ag), _f32(gram), _f32(uvec_p)
+    E, n_l, V = Ag.shape
+    N = out_ptr.numel() - 1
+    tbw = torch.empty(E, V, device=Ag.device, dtype=torch.float32)
+    _call("lcao_triplet_gemm", _p(Ag), _p(gram), _p(uvec_p), _p(in_ptr), _p(in_pos), _p(out_ptr), N, E, V, n_l, _p(tbw),
+          _stream())
+    return tbw
 
 
 def triplet_sum(A, gate, uvec, order, src_p, in_ptr, in_pos):

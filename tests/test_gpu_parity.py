@@ -212,9 +212,10 @@ def _oracle_run(sd, kw, graph_cpu, dtype=torch.float32):
     return out, tr
 
 
-@pytest.mark.parametrize("width,fused", [(32, True), (32, False), (64, True), (128, True), (128, False)])
+@pytest.mark.parametrize("width,fused,exact", [(32, True, False), (32, False, False), (64, True, False),
+                                               (128, True, False), (128, True, True), (128, False, False)])
 @pytest.mark.parametrize("valence", [False, True])
-def test_fused_mfma_path_vs_oracle(dev, width, fused, valence):
+def test_fused_mfma_path_vs_oracle(dev, width, fused, exact, valence):
     """The MFMA kernels (C = V in {32,64,128}) and the generic kernels against the oracle on random cells."""
     from lcaonet_amd.data.synthetic import random_periodic_cells
     kw = dict(emb_size=64, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0,
@@ -223,7 +224,7 @@ def test_fused_mfma_path_vs_oracle(dev, width, fused, valence):
     g = random_periodic_cells(3, 14, 6.2, 0.99 * 5.0, seed=width)
     want, wtr = _oracle_run(sd, kw, g.to_dict())
     tr = {}
-    got = m(g.to(dev), fused=fused, trace=tr)
+    got = m(g.to(dev), fused=fused, trace=tr, exact_norm=exact)
     order = tr["order"].long().cpu()
     assert relerr(tr["three_body_w1"], wtr["three_body_w1"][order]) <= TOL
     assert relerr(tr["x1"], wtr["x1"]) <= TOL
