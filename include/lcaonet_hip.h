@@ -134,7 +134,9 @@ int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* or
                             const float* valence_ed /* (E,D) orig order, nullable */, const float* W1,
                             const float* W2, const float* gate /* (N,V) sigmoid(xk), nullable */,
                             const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, int valence,
-                            float* A, float* B, float* Bv, float* Ag, float* gram, void* stream);
+                            float* A, float* B, float* Bv, float* Ag, float* gram,
+                            void* workspace /* device, >= 8 bytes: tile-queue counters, zeroed by the call */,
+                            size_t ws_bytes, void* stream);
 
 /* lcaonet.py:173-189 as one small fp32-MFMA GEMM per centre node (no LDS, no T-sized tensor):
  *   tbw[p,:] = sum_{q in In(s), q != p}  sum_l  Y_l(u_p.u_q) / max(sqrt(Y^T G_q Y), 1e-12) * Ag[q,l,:]
@@ -155,6 +157,10 @@ int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, co
                            float* msg, void* stream);
 
 size_t lcao_lds_bytes_coeff_mlp(int C, int V, int valence);
+
+/* Diagnostics only (tools/clock_probe.py): buffer of 2 x uint64 per wave of lcao_coeff_mlp_contract receiving
+ * {shader cycles, 100 MHz ticks} of the wave's tile loop; NULL (default) disables the stamps entirely. */
+void lcao_debug_set_clock_probe(void* buf);
 
 #ifdef __cplusplus
 }

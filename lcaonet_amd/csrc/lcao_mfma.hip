@@ -14,11 +14,32 @@
 //     row r — which is exactly the B-operand layout of the NEXT layer (k = 16t + 4q + j at step (t, j)), so a
 //     chain of layers runs register to register: no LDS round trip, no barrier, no transposition.
 //   Waves never talk to each other after the weights are staged: one __syncthreads per kernel.
+#include <cstdlib>
+
 #include "lcao_common.h"
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Diagnostic ablation builds (tools/k2_ablate.py; never defined in the shipped library):
+//   LCAO_ABL & 1: activations replaced by identity     & 2: coefficient rows loaded once per tile, not per orbital
+//   LCAO_ABL & 4: weight fragments read once per feature-tile pair instead of once per k chunk (1/KT of the LDS reads)
+//   LCAO_ABL & 8: WITHOUT the s_setprio(1) around each layer's MFMA stream     & 16: static s_setprio(1) for waves 4-7
+#ifndef LCAO_ABL
+#define LCAO_ABL 0
+#endif
+#if LCAO_ABL & 1
+#define K2_SILU(x) (x)
+#else
+#define K2_SILU(x) lcao_silu(x)
+#endif
+
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// Diagnostic hook (tools/clock_probe.py): when set, lane 0 of every wave of k_coeff_mlp stores
+// {delta s_memtime (shader cycles), delta s_memrealtime (100 MHz ticks)} of its whole tile loop into this buffer
+// (4 x uint64 per wave).  NULL in production: the guarded stamps then never execute.
+static unsigned long long* g_clock_probe = nullptr;
+extern "C" void lcao_debug_set_clock_probe(void* buf) { g_clock_probe = (unsigned long long*)buf; }
 
 static int g_num_cu = 0;
 static inline int lcao_num_cu() {
@@ -49,20 +70,34 @@ template <int KT, int MT>
 __device__ __forceinline__ void mfma_layer(const float* __restrict__ wl, int ldw /*K+4*/, int r, int q,
                                            const f32x4v (&in)[KT], f32x4v (&out)[MT]) {
   static_assert(MT % 2 == 0, "feature tiles are processed in pairs");
+  // Flattened (tile pair, k chunk) sequence with the weight fragments of step t+1 requested from LDS before the
+  // 8 MFMAs of step t are issued: ~256 cycles of matrix work cover the ds_read_b128 latency (reading a fragment
+  // right before its first MFMA stalled the pipe for ~25 % of the kernel).
+  constexpr int STEPS = (MT / 2) * KT;
+  const float* w0 = wl + r * ldw + 4 * q;
+  f32x4v n0 = *(const f32x4v*)(w0);
+  f32x4v n1 = *(const f32x4v*)(w0 + 16 * ldw);
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the prologue reads form their own group (see below)
 #pragma unroll
-  for (int m = 0; m < MT; m += 2) {
-    const float* w0 = wl + (16 * m + r) * ldw + 4 * q;
-    const float* w1 = w0 + 16 * ldw;
-#pragma unroll
-    for (int a = 0; a < KT; ++a) {
-      f32x4v f0 = *(const f32x4v*)(w0 + 16 * a);
-      f32x4v f1 = *(const f32x4v*)(w1 + 16 * a);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        out[m] = MFMA16(f0[b], in[a][b], out[m]);
-        out[m + 1] = MFMA16(f1[b], in[a][b], out[m + 1]);
+  for (int t = 0; t < STEPS; ++t) {
+    const int m = 2 * (t / KT), a = t % KT;
+    const f32x4v f0 = n0, f1 = n1;
+    if (t + 1 < STEPS) {
+      const int m2 = 2 * ((t + 1) / KT), a2 = (t + 1) % KT;
+      if (!(LCAO_ABL & 4) || a2 == 0) {  // ablation: one fragment pair per tile pair (1/KT of the LDS reads)
+        n0 = *(const f32x4v*)(w0 + (16 * m2) * ldw + 16 * a2);
+        n1 = *(const f32x4v*)(w0 + (16 * m2 + 16) * ldw + 16 * a2);
       }
     }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      out[m] = MFMA16(f0[b], in[a][b], out[m]);
+      out[m + 1] = MFMA16(f1[b], in[a][b], out[m + 1]);
+    }
+    // pin the issue order: the two ds_read_b128 of step t+1 first, then this step's 8 MFMAs (hipcc otherwise sinks
+    // the reads next to their first use and waits on them with one MFMA of cover)
+    if (t + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
   }
 }
 
@@ -199,8 +234,8 @@ extern "C" int lcao_dense(const float* X, int64_t ldx, const float* W, const flo
 //   HBM per edge: read 4*D*C (cst) + 4*D (rb); write 4*(n_l+1)*V.   FLOPs per edge: 2*D*(C*V + V*V).
 // LDS: W1 (V x (C+4)) and W2 (V x (V+4)) fp32, staged once per persistent workgroup.
 // ===================================================================================================
-template <int C, int V, int NL>
-__global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst, const float* __restrict__ rb,
+template <int C, int V, int NL, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__ cst, const float* __restrict__ rb,
                                                    const int32_t* __restrict__ order,
                                                    const int32_t* __restrict__ l_of_d,
                                                    const float* __restrict__ wmul /* (E,D) or null */,
@@ -208,7 +243,8 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
                                                    int64_t E, int D, int accumulate, float* __restrict__ A,
                                                    float* __restrict__ Bout, const float* __restrict__ gate,
                                                    const int32_t* __restrict__ src_p, float* __restrict__ Ag,
-                                                   float* __restrict__ gram) {
+                                                   float* __restrict__ gram, unsigned* __restrict__ tile_counter,
+                                                   unsigned long long* __restrict__ clk) {
   constexpr int KT1 = C / 16, MT = V / 16;
   extern __shared__ float lds[];
   float* w1s = lds;
@@ -219,7 +255,22 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t n_tiles = (E + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+  constexpr int WAVES = THREADS / 64;
+  unsigned long long t0 = 0, r0 = 0;
+  if (clk) {
+    t0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  // Dynamic tile queue: the first tile of a wave is static, every further one is drawn from a device-scope
+  // counter (zeroed by the launcher).  With a static split the two waves that share a SIMD finished 1.5 ms apart
+  // (the older wave wins MFMA arbitration, completes its share early and leaves the other to run alone);
+  // drawing tiles keeps both resident until the queue is empty.  Every wave exits once it draws tile >= n_tiles.
+#if LCAO_ABL & 16
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
+  const int64_t first_dynamic = (int64_t)gridDim.x * WAVES;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  for (; tile < n_tiles;) {
     const int64_t p = tile * 16 + r;
     const bool valid = p < E;
     const int64_t pc = valid ? p : E - 1;
@@ -243,20 +294,34 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
       f32x4v h[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) h[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      // the wave in an MFMA stream outranks its SIMD partner's VALU phase for the shared vector issue port
+      // (+2 % measured, tools/k2_ablate.py); LCAO_ABL & 8 removes it for A/B runs
+#if !(LCAO_ABL & 8)
+      __builtin_amdgcn_s_setprio(1);
+#endif
       mfma_layer<KT1, MT>(w1s, C + 4, r, q, x, h);
+#if !(LCAO_ABL & 8)
+      __builtin_amdgcn_s_setprio(0);
+#endif
       // prefetch the next orbital's coefficient row while layer 2 runs
-      if (d + 1 < D) {
+      if (d + 1 < D && !(LCAO_ABL & 2)) {
 #pragma unroll
         for (int a = 0; a < KT1; ++a) x[a] = *(const f32x4v*)(xrow + (d + 1) * C + 16 * a);
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[m][j] = lcao_silu(h[m][j]);
+        for (int j = 0; j < 4; ++j) h[m][j] = K2_SILU(h[m][j]);
       f32x4v o[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#if !(LCAO_ABL & 8)
+      __builtin_amdgcn_s_setprio(1);
+#endif
       mfma_layer<MT, MT>(w2s, V + 4, r, q, h, o);
+#if !(LCAO_ABL & 8)
+      __builtin_amdgcn_s_setprio(0);
+#endif
       float w = rbrow[d];
       if (wmul) w *= wmul[e * D + d];
       const int l = l_of_d[d];  // wave-uniform
@@ -266,7 +331,7 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ll][m][j] += w * lcao_silu(o[m][j]);
+            for (int j = 0; j < 4; ++j) acc[ll][m][j] += w * K2_SILU(o[m][j]);
         }
       }
     }
@@ -331,40 +396,78 @@ __global__ __launch_bounds__(256) void k_coeff_mlp(const float* __restrict__ cst
         }
       }
     }
+    unsigned nxt = 0;
+    if (lane == 0) nxt = atomicAdd(tile_counter, 1u);
+    tile = first_dynamic + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
   }
+  if (clk && lane == 0) {
+    unsigned long long* o = clk + 4 * ((size_t)blockIdx.x * WAVES + wave);
+    o[0] = __builtin_amdgcn_s_memtime() - t0;
+    o[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    o[2] = r0;  // absolute 100 MHz stamps: loop start / end (kernel span = max end - min start)
+    o[3] = r0 + o[1];
+  }
+}
+
+// block size of k_coeff_mlp: 512 threads = 2 waves per SIMD sharing the LDS weights (one wave's SiLU / accumulate
+// VALU work runs under the other's MFMAs) when the register budget allows (n_l <= 3: <= 256 VGPRs), else 256.
+// LCAO_K2_THREADS=256|512 overrides (benchmarking).
+static int coeff_mlp_threads(int n_l) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("LCAO_K2_THREADS");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 256 || forced == 512) return forced;
+  return n_l <= 3 ? 512 : 256;
+}
+
+template <int C, int V, int NL, int THREADS>
+static int launch_coeff_mlp_t(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                              const float* wmul, const float* W1, const float* W2, int64_t E, int D, int accumulate,
+                              float* A, float* Bout, const float* gate, const int32_t* src_p, float* Ag,
+                              float* gram, unsigned* counter, hipStream_t st) {
+  size_t lds = (size_t(V) * (C + 4) + size_t(V) * (V + 4)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_coeff_mlp<C, V, NL, THREADS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return int(e);
+    attr_set = true;
+  }
+  constexpr int WAVES = THREADS / 64;
+  int64_t tiles = (E + 15) / 16;
+  int64_t groups = (tiles + WAVES - 1) / WAVES;
+  int64_t per_cu = (lds > 80 * 1024) ? 1 : 2;
+  int64_t cap = (int64_t)lcao_num_cu() * per_cu;
+  if (groups > cap) groups = cap;
+  hipError_t me = hipMemsetAsync(counter, 0, sizeof(unsigned), st);  // re-armed on every call, stream-ordered
+  if (me != hipSuccess) return int(me);
+  hipLaunchKernelGGL((k_coeff_mlp<C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb, order,
+                     l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, g_clock_probe);
+  return lcao_launch_status();
 }
 
 template <int C, int V, int NL>
 static int launch_coeff_mlp(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
                             const float* wmul, const float* W1, const float* W2, int64_t E, int D, int accumulate,
                             float* A, float* Bout, const float* gate, const int32_t* src_p, float* Ag, float* gram,
-                            hipStream_t st) {
-  size_t lds = (size_t(V) * (C + 4) + size_t(V) * (V + 4)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_coeff_mlp<C, V, NL>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return int(e);
-    attr_set = true;
-  }
-  int64_t tiles = (E + 15) / 16;
-  int64_t groups = (tiles + 3) / 4;
-  int64_t per_cu = (lds > 80 * 1024) ? 1 : 2;
-  int64_t cap = (int64_t)lcao_num_cu() * per_cu;
-  if (groups > cap) groups = cap;
-  hipLaunchKernelGGL((k_coeff_mlp<C, V, NL>), dim3((unsigned)groups), dim3(256), lds, st, cst, rb, order, l_of_d,
-                     wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram);
-  return lcao_launch_status();
+                            unsigned* counter, hipStream_t st) {
+  if (coeff_mlp_threads(NL) == 512)
+    return launch_coeff_mlp_t<C, V, NL, 512>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate,
+                                             src_p, Ag, gram, counter, st);
+  return launch_coeff_mlp_t<C, V, NL, 256>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate,
+                                           src_p, Ag, gram, counter, st);
 }
 
 template <int C, int V>
 static int dispatch_coeff_mlp_nl(int n_l, const float* cst, const float* rb, const int32_t* order,
                                  const int32_t* l_of_d, const float* wmul, const float* W1, const float* W2,
                                  int64_t E, int D, int accumulate, float* A, float* Bout, const float* gate,
-                                 const int32_t* src_p, float* Ag, float* gram, hipStream_t st) {
+                                 const int32_t* src_p, float* Ag, float* gram, unsigned* counter, hipStream_t st) {
 #define CM_NL(NL_) \
   case NL_:        \
-    return launch_coeff_mlp<C, V, NL_>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, st)
+    return launch_coeff_mlp<C, V, NL_>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, st)
   switch (n_l) {
     CM_NL(1); CM_NL(2); CM_NL(3); CM_NL(4);
 #undef CM_NL
@@ -381,7 +484,7 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
                                        const int32_t* l_of_d, const float* valence_ed, const float* W1,
                                        const float* W2, const float* gate, const int32_t* src_p, int64_t n_edges,
                                        int n_orb, int C, int V, int n_l, int valence, float* A, float* B, float* Bv,
-                                       float* Ag, float* gram, void* stream) {
+                                       float* Ag, float* gram, void* workspace, size_t ws_bytes, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   if (n_orb <= 0 || C <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
@@ -389,6 +492,9 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
   LCAO_CHECK_PTR(B);
   if (valence) { LCAO_CHECK_PTR(valence_ed); LCAO_CHECK_PTR(Bv); LCAO_CHECK_PTR(A); }
   if (Ag) { LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(gram); } else { LCAO_CHECK_PTR(A); }
+  LCAO_CHECK_PTR(workspace);
+  if (ws_bytes < 2 * sizeof(unsigned)) return LCAO_ERR_INVALID;  // one tile-queue counter per pass
+  unsigned* ctr = (unsigned*)workspace;
   hipStream_t st = (hipStream_t)stream;
   int rc = LCAO_ERR_UNSUPPORTED;
   // no valence: one pass, finalised (gated + Gram) directly.  valence: pass 1 writes the raw A of the plain half
@@ -397,12 +503,13 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
   if (C == C_ && V == V_) {                                                                                        \
     if (!valence)                                                                                                  \
       return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, B,  \
-                                           gate, src_p, Ag, Ag ? gram : nullptr, st);                              \
+                                           gate, src_p, Ag, Ag ? gram : nullptr, ctr, st);                         \
     rc = dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, B,      \
-                                       nullptr, nullptr, nullptr, nullptr, st);                                    \
+                                       nullptr, nullptr, nullptr, nullptr, ctr, st);                               \
     if (rc != LCAO_OK) return rc;                                                                                  \
     return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, valence_ed, W1, W2 + (size_t)V_ * V_,        \
-                                         n_edges, n_orb, 1, A, Bv, gate, src_p, Ag, Ag ? gram : nullptr, st);      \
+                                         n_edges, n_orb, 1, A, Bv, gate, src_p, Ag, Ag ? gram : nullptr, ctr + 1,  \
+                                         st);                                                                      \
   }
   CM_CASE(128, 128)
   CM_CASE(64, 64)

@@ -212,8 +212,9 @@ def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence,
     gram = torch.empty(E, 10, device=dev, dtype=torch.float32) if gated else None
     if gated:
         gate = _f32(gate, "gate")
+    ws = torch.empty(2, device=dev, dtype=torch.int32)  # tile-queue counters (the library zeroes them on the stream)
     _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(order), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2), _p(gate),
-          _p(src_p), E, D, C, V, n_l, int(valence), _p(A), _p(B), _p(Bv), _p(Ag), _p(gram), _stream())
+          _p(src_p), E, D, C, V, n_l, int(valence), _p(A), _p(B), _p(Bv), _p(Ag), _p(gram), _p(ws), 8, _stream())
     return (Ag if gated else A), gram, B, Bv
 
 
