@@ -62,20 +62,39 @@ def cpu_baseline(max_seconds: float = 25.0) -> dict:
     g = random_periodic_cells(32, 20, 7.4, 0.99 * 5.0, seed=1234).to_dict()
     E = g["edge_index"].shape[1]
     cfg = O.OracleConfig(**kw)
-    cores = torch.get_num_threads()
-    times = []
+    # the literal dataflow is a chain of small/medium ATen ops: more threads is not faster.  Try a few thread counts
+    # within the time budget and report the best one (cores = threads actually used for the reported number).
+    ncpu = os.cpu_count() or 1
+    candidates = sorted({min(ncpu, c) for c in (8, 16, 32, ncpu)})
+    best = None
     t_start = time.time()
     with torch.no_grad():
-        O.forward(sd, cfg, g)  # warm-up
-        while len(times) < 5 and (time.time() - t_start) < max_seconds:
-            t0 = time.time()
-            O.forward(sd, cfg, g)
-            times.append(time.time() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+        for cores in candidates:
+            if best is not None and (time.time() - t_start) > max_seconds:
+                break
+            torch.set_num_threads(cores)
+            O.forward(sd, cfg, g)  # warm-up
+            times = []
+            for _ in range(3):
+                t0 = time.time()
+                O.forward(sd, cfg, g)
+                times.append(time.time() - t0)
+            med = sorted(times)[1]
+            if best is None or med < best[0]:
+                best = (med, cores)
+    med, cores = best
     return {"value": E / med, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": f"BASELINE config 1: LCAONet(emb_size=64,n_interaction=2,cutoff=5.0) forward on 32x20-atom cells, "
-                      f"E={E}, median of {len(times)} runs, torch CPU threads={cores}"}
+                      f"E={E}, median of 3 runs at the best of {candidates} torch CPU threads (host has {ncpu})"}
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json), or None."""
+    path = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
+    try:
+        return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -155,18 +174,21 @@ def main():
             flop = 2.0 * D * (C * V + V * V) * E
             achieved = flop / (per_launch_ms * 1e-3) / 1e12
             roof = {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": pmc_traffic(name) if args.workload == "cfg2" else None,
                     "avg_launch_ms": round(per_launch_ms, 4), "launches": calls,
                     "algorithmic_bytes_per_launch": (4 * D * C + 4 * D + 4 * (n_l + 1) * V) * E}
         # the HBM-bound group of the north star ("edge-basis + scatter path"): three-body kernel
         roof_hbm = None
-        if "lcao_triplet_sum" in ksum:
-            calls, ms = ksum["lcao_triplet_sum"]
+        tk = "lcao_triplet_gemm" if "lcao_triplet_gemm" in ksum else "lcao_triplet_sum"
+        if tk in ksum:
+            calls, ms = ksum[tk]
             per_launch_ms = ms / calls
-            byts = (4 * n_l * V + 4 * V + 12 + 8) * E + 4 * V * N  # A rows + tbw write + uvec/idx + gate rows
+            byts = (4 * n_l * V + 40 + 12 + 4 * V) * E  # Ag rows + gram + unit vector read, tbw written
             gbs = byts / (per_launch_ms * 1e-3) / 1e9
-            roof_hbm = {"kernel": "lcao_triplet_sum", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            roof_hbm = {"kernel": tk, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                        "traffic": pmc_traffic("lcao_triplet_gemm") if args.workload == "cfg2" else None,
                         "avg_launch_ms": round(per_launch_ms, 4), "launches": calls,
                         "algorithmic_bytes_per_launch": byts}
         line = {
