@@ -204,52 +204,64 @@ class LCAOInteraction(nn.Module):
     @torch.no_grad()
     def forward_fused(self, x: Tensor, cst: Tensor, valence_ed: Tensor | None, rb: Tensor, uvec: Tensor,
                       ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
-                      trace: dict | None = None, exact_norm: bool = False) -> Tensor:
-        """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1."""
+                      trace: dict | None = None, exact_norm: bool = False, n_own: int | None = None,
+                      e_own: int | None = None) -> Tensor:
+        """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1.
+
+        n_own / e_own (sharded graphs, lcaonet_amd/shard.py): only the first n_own nodes are centres to update and
+        only the first e_own edges of p-space carry messages; the remaining (ghost) nodes and their out-edges feed the
+        three-body and two-body terms.  Returns the new state of the n_own centre nodes."""
         V = self.emb_size_conv
+        N = x.size(0)
+        n_own = N if n_own is None else n_own
+        e_own = ctx.n_edges if e_own is None else e_own
         if fused is None:
             fused = self._fusable(cst.shape[-1])
         wn, bn_ = self.node_weight.weight.detach(), self.node_weight.bias.detach()
         xs = ops.dense(x, wn[:V], bn_[:V])
         gate = ops.dense(x, wn[V:], bn_[V:], ops.ACT_SIGMOID)           # sigmoid(xk), gathered per triplet
         w1 = self.f_node[0].weight.detach()
-        Ps = ops.dense(xs, w1[:, :V].contiguous(), self.f_node[0].bias.detach())
+        Ps = ops.dense(xs[:n_own], w1[:, :V].contiguous(), self.f_node[0].bias.detach())
         Pt = ops.dense(xs, w1[:, V:].contiguous())
-        # coefficient MLP + radial contraction, then the three-body term
+        out_ptr, in_ptr = ctx.out_ptr[: n_own + 1], ctx.in_ptr[: n_own + 1]
+        src_own, dst_own = ctx.src_p[:e_own], ctx.dst_p[:e_own]
+        # coefficient MLP + radial contraction (all local edges), then the three-body term (owned centres)
         if fused:
             Ag, gram, B, Bv = ops.coeff_mlp_contract(
                 cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
                 self.f_coeffs[2].weight.detach(), n_l, self.add_valence,
                 gate=None if exact_norm else gate, src_p=ctx.src_p)
             if exact_norm:   # per-triplet V-long norm (validation of the Gram-matrix form)
-                tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, ctx.in_ptr, ctx.in_pos)
+                tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
             else:
-                tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
+                tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
         else:
             cstf = run_mlp(self.f_coeffs, cst)
             A, B, Bv = ops.coeff_contract(cstf, rb, ctx.order, l_of_d, valence_ed, V, n_l, self.add_valence)
-            tbw = ops.triplet_sum(A, gate, uvec, ctx.order, ctx.src_p, ctx.in_ptr, ctx.in_pos)
+            tbw = ops.triplet_sum(A, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
         if trace is not None:
             trace["three_body_w"] = tbw  # p-space
+        B = B[:e_own]
+        Bv = Bv[:e_own] if Bv is not None else None
         # two-body term and messages
         if fused and not self.add_valence:
             bw = ops.edge_lcao_weight(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach())
-            msg = ops.edge_node_message(bw, Ps, Pt, ctx.src_p, ctx.dst_p, self.f_node[2].weight.detach(),
+            msg = ops.edge_node_message(bw, Ps, Pt, src_own, dst_own, self.f_node[2].weight.detach(),
                                         self.f_node[2].bias.detach())
-            agg = ops.segment_sum(msg, ctx.out_ptr)
+            agg = ops.segment_sum(msg, out_ptr)
         else:
             ft = run_mlp(self.f_three, tbw)
             lw = ops.edge_combine(ft, B, Bv)
             bw = self.basis_weight(lw)
             code = act_code(self.f_node[1])
             if code == ops.ACT_SILU:
-                h1 = ops.pair_silu(Ps, Pt, ctx.src_p, ctx.dst_p)
+                h1 = ops.pair_silu(Ps, Pt, src_own, dst_own)
             else:
-                h1 = self.f_node[1](Ps[ctx.src_p.long()] + Pt[ctx.dst_p.long()])
+                h1 = self.f_node[1](Ps[src_own.long()] + Pt[dst_own.long()])
             code2 = act_code(self.f_node[3])
             h2 = self.f_node[2](h1, act=code2) if code2 is not None else self.f_node[3](self.f_node[2](h1))
-            agg = ops.segment_sum(bw, ctx.out_ptr, h2)
-        return self.out_weight(agg, residual=x)
+            agg = ops.segment_sum(bw, out_ptr, h2)
+        return self.out_weight(agg, residual=x[:n_own])
 
 
 class LCAOOut(nn.Module):
@@ -373,6 +385,65 @@ class LCAONet(BaseMPNN):
         graph[GraphKeys.Angles_3b] = ops.triplet_angles(vec, graph[GraphKeys.Edge_idx_st_3b],
                                                         graph[GraphKeys.Edge_idx_ks_3b])
         return graph
+
+    # --- one graph sharded over several GPUs (lcaonet_amd/shard.py) ---------------------------------------------
+    @torch.no_grad()
+    def forward_sharded(self, plan, exchange_fn=None, reduce_fn=None, group=None, fused: bool | None = None):
+        """This rank's part of forward() on a graph partitioned by centre node.  `plan` = shard.make_plans(...)[rank].
+        Collectives: L-1 all-gathers of boundary node rows (exchange_fn, default shard.exchange_ghosts over `group`)
+        and one all-reduce of the (B, out) per-graph partial sums (reduce_fn).  Returns the global (B, out) result
+        (identical on every rank) or ((B, out), forces of the owned nodes)."""
+        from .. import shard
+
+        if self.regress_forces and not self.direct_forces:
+            raise NotImplementedError("autograd forces: backward kernels not built yet (SURVEY.md §8f-3)")
+        if self.training:
+            raise NotImplementedError("forward_sharded: eval mode only (BatchNorm batch statistics would need a collective)")
+        exchange_fn = exchange_fn or (lambda x_own: shard.exchange_ghosts(plan, x_own, group))
+        reduce_fn = reduce_fn or (lambda part: shard.reduce_graph_outputs(part, group))
+        graph = plan.graph
+        z, pos = graph[GraphKeys.Z], graph[GraphKeys.Pos]
+        idx_s, idx_t = graph[GraphKeys.Edge_idx]
+        n_own, e_own = plan.n_own, plan.e_own
+        ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], z.size(0))
+        graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
+        dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
+        rb = self.rbf(dist)
+        x, cst = self.emb_layer.forward_species(z, ctx)   # static inputs only: ghosts need no exchange for x0
+        valence_ed = self.valence_mask.per_edge(z, idx_t) if self.add_valence else None
+
+        def layer_fn(i, x_local):
+            return self.int_layers[i].forward_fused(x_local, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l,
+                                                    fused, None, False, n_own, e_own)
+
+        x_own = shard.run_sharded_layers(plan, x, self.n_interaction, layer_fn, exchange_fn)
+        # output head on the owned nodes; per-graph reduction = local partial sums + one small all-reduce
+        batch_own = graph[GraphKeys.Batch_idx][:n_own]
+        prop = run_mlp(self.out_layer.out_lin, x_own)
+        part = scatter(prop, batch_own, dim=0, dim_size=plan.n_graphs, reduce="sum")
+        z_own = z[:n_own]
+        ones = torch.ones(n_own, 1, device=prop.device)
+        extra = [scatter(ones, batch_own, dim=0, dim_size=plan.n_graphs, reduce="sum")]
+        if self.pp_layer.atomref is not None:
+            extra.append(scatter(self.pp_layer.atomref[z_own].float().contiguous(), batch_own, dim=0,
+                                 dim_size=plan.n_graphs, reduce="sum"))
+        tot = reduce_fn(torch.cat([part] + extra, dim=1))
+        out, cnt = tot[:, : self.out_size], tot[:, self.out_size: self.out_size + 1]
+        ext = self.out_layer.is_extensive
+        if not ext:
+            out = out / cnt.clamp(min=1)
+        if self.pp_layer.atomref is not None:
+            aref = tot[:, self.out_size + 1:]
+            out = out + (aref if self.pp_layer.is_extensive else aref / cnt.clamp(min=1))
+        if self.pp_layer.mean is not None:
+            out = out + (self.pp_layer.mean.unsqueeze(0) * cnt if self.pp_layer.is_extensive else self.pp_layer.mean.unsqueeze(0))
+        if self.regress_forces:  # direct forces of the owned centres (their out-edges are all local)
+            own_e = idx_s < n_own
+            es, et = idx_s[own_e], idx_t[own_e]
+            xl = torch.cat([x_own, exchange_fn(x_own)], dim=0) if plan.n_ghost else x_own
+            f = run_mlp(self.out_layer.out_lin_force, torch.cat([xl[es], xl[et]], dim=-1)) * uvec[own_e]
+            return out, scatter(f, es, dim=0, dim_size=n_own)
+        return out
 
     # --- forward ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -218,19 +218,23 @@ def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence,
     return (Ag if gated else A), gram, B, Bv
 
 
-def triplet_gemm(Ag, gram, uvec_p, in_ptr, in_pos, out_ptr):
+def triplet_gemm(Ag, gram, uvec_p, in_ptr, in_pos, out_ptr, n_edges=None):
+    """Centre nodes = the out_ptr.numel()-1 first nodes; writes tbw rows [0, out_ptr[-1]) (= n_edges when given)."""
     Ag, gram, uvec_p = _f32(Ag), _f32(gram), _f32(uvec_p)
     E, n_l, V = Ag.shape
     N = out_ptr.numel() - 1
+    E = E if n_edges is None else n_edges
     tbw = torch.empty(E, V, device=Ag.device, dtype=torch.float32)
     _call("lcao_triplet_gemm", _p(Ag), _p(gram), _p(uvec_p), _p(in_ptr), _p(in_pos), _p(out_ptr), N, E, V, n_l, _p(tbw),
           _stream())
     return tbw
 
 
-def triplet_sum(A, gate, uvec, order, src_p, in_ptr, in_pos):
+def triplet_sum(A, gate, uvec, order, src_p, in_ptr, in_pos, n_edges=None):
+    """n_edges: compute only the first n_edges out-edges (sharded graphs: the owned prefix of p-space)."""
     A, gate, uvec = _f32(A), _f32(gate), _f32(uvec)
     E, n_l, V = A.shape
+    E = E if n_edges is None else n_edges
     tbw = torch.empty(E, V, device=A.device, dtype=torch.float32)
     _call("lcao_triplet_sum", _p(A), _p(gate), _p(uvec), _p(order), _p(src_p), _p(in_ptr), _p(in_pos), E, V, n_l,
                                     _p(tbw), _stream())
