@@ -150,6 +150,20 @@ def main():
             elapsed = time.perf_counter() - t0
             ksum = prof.summary()
     assert bool(torch.isfinite(out).all())
+    # secondary measurement (rank-local, after the headline region): the same forward with cst_mode="pair"
+    pair_ms = None
+    try:
+        with torch.no_grad():
+            out_pair = model(batch, cst_mode="pair")
+            pair_err = float((out_pair - out).abs().max() / out.abs().max())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                model(batch, cst_mode="pair")
+            torch.cuda.synchronize()
+            pair_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+    except NotImplementedError:
+        pass
 
     t = torch.tensor([elapsed, float(E)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -204,6 +218,11 @@ def main():
             "roofline": roof, "roofline_hbm": roof_hbm,
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(ksum.items(), key=lambda kv: -kv[1][1])},
         }
+        if pair_ms is not None:
+            line["pair_table_mode"] = {
+                "note": "NOT the headline: LCAONet.forward(cst_mode='pair') — f_coeffs evaluated on the (z_s,z_t) species-pair "
+                        "table (SURVEY.md 8f-2) instead of per edge; same outputs", "ms_per_step_rank0": round(pair_ms, 3),
+                "edges_per_s_rank0": E / (pair_ms * 1e-3), "max_rel_diff_vs_headline_output": pair_err}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

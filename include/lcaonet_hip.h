@@ -145,6 +145,14 @@ int lcao_triplet_gemm(const float* Ag, const float* gram, const float* uvec_p, c
                       const int32_t* in_pos, const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int V, int n_l,
                       float* tbw, void* stream);
 
+/* Species-pair form of lcaonet.py:170-183,200 (eval mode, no valence): with
+ * Tf[(z_s*zdim + z_t), d, :] = f_coeffs(cst(z_s, z_t))[d, :] precomputed on the (zdim^2, D, V) pair table,
+ *   A[p,l,:] = sum_{d in l} rb[e,d] * Tf[pair(p),d,:];  writes Ag = A * gate[src_p], B = sum_l A, gram = A A^T
+ * exactly as lcao_coeff_mlp_contract does (same consumers), without the 2*D*(C*V+V*V) flop per edge. */
+int lcao_pair_contract(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d, const int64_t* z,
+                       const int32_t* src_p, const int32_t* dst_p, const float* gate, int64_t n_edges, int n_orb, int V,
+                       int n_l, int zdim, float* Ag, float* B, float* gram, void* stream);
+
 /* lcaonet.py:192-204 + basis_weight (:209) in ONE kernel (no valence):
  *   bw[p,:] = normalize( (1 + tbw[p,:] W3^T) * B[p,:] ) Wb^T          W3, Wb (V, V) */
 int lcao_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges, int V,

@@ -75,6 +75,15 @@ __device__ __forceinline__ float lcao_cutoff_eval(float r, float rc, int kind) {
   }
 }
 
+// sum within each row of 16 lanes (DPP: two quad permutes, row_half_mirror, row_mirror), result in every lane of the row
+__device__ __forceinline__ float lcao_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 // sum across the 64 lanes of a wave, result in every lane (DPP within rows of 16, then readlane across rows)
 __device__ __forceinline__ float lcao_wave_sum(float v) {
   v += __shfl_xor(v, 1);

@@ -552,3 +552,123 @@ extern "C" const char* lcao_error_string(int code) {
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "lcaonet_hip: unknown error";
 }
+
+// ---------------------------------------------------------------------------------------------------
+// lcao_pair_contract — species-pair form of f_coeffs + radial contraction.
+// cst[e] is a function of (z_s, z_t) only (embed.py:246-249) and every layer applies a row-wise MLP to the same
+// cst, so f_coeffs(cst)[e] = Tf[z_s, z_t] with Tf a ((Z+1)^2, D, V) table (5.6 MB at Z=36: L2 / Infinity-Cache
+// resident).  Per edge p:  A[l,:] = sum_{d in l} rb[e,d] * Tf[pair,d,:],  B = sum_l A,  gram = A A^T,
+// Ag[l,:] = A[l,:] * gate[src,:].   One wave per edge, lanes over V (R values per lane); 2.1 KB written per edge.
+// ---------------------------------------------------------------------------------------------------
+// 16 lanes per edge (4 edges per wave); a lane owns CH = V/16 channels as float4 chunks: chunk c covers channels
+// 64*c + 4*sub .. +3, so a 16-lane row reads / writes 256 contiguous bytes per chunk.
+template <int V, int NL>
+__global__ __launch_bounds__(256) void k_pair_contract(const float* __restrict__ Tf, const float* __restrict__ rb,
+                                                       const int32_t* __restrict__ order,
+                                                       const int32_t* __restrict__ l_of_d,
+                                                       const int64_t* __restrict__ z,
+                                                       const int32_t* __restrict__ src_p,
+                                                       const int32_t* __restrict__ dst_p,
+                                                       const float* __restrict__ gate, int64_t E, int D, int zdim,
+                                                       float* __restrict__ Ag, float* __restrict__ B,
+                                                       float* __restrict__ gram) {
+  constexpr int NC = (V + 63) / 64;  // float4 chunks per lane
+  const int sub = threadIdx.x & 15, rowi = (threadIdx.x & 63) >> 4;
+  int64_t p0 = ((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) * 4;   // wave-uniform: 4 edges per wave
+  const int64_t stride = (((int64_t)gridDim.x * blockDim.x) >> 6) * 4;
+  for (; p0 < E; p0 += stride) {   // whole waves stay converged for the DPP reductions; rows past E are masked
+    const int64_t p = p0 + rowi;
+    const bool valid = p < E;
+    const int64_t pc = valid ? p : E - 1;
+    const int64_t e = order ? order[pc] : pc;
+    const int s = src_p[pc];
+    const int64_t pair = z[s] * zdim + z[dst_p[pc]];
+    const float* t = Tf + pair * (int64_t)D * V + 4 * sub;
+    f32x4 a[NL][NC];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d) {
+      const float w = rb[e * D + d];
+      const int l = l_of_d[d];  // uniform
+      f32x4 v[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        v[c] = (64 * c + 4 * sub) < V ? *(const f32x4*)(t + d * V + 64 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ll = 0; ll < NL; ++ll)
+        if (l == ll) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) a[ll][c] += w * v[c];
+        }
+    }
+    // Gram (upper triangle of a 4x4, row-major): in-lane partial + 16-lane row reduction
+    float g[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) g[i] = 0.f;
+    {
+      int gi = 0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int l2 = l; l2 < 4; ++l2) {
+          if (l < NL && l2 < NL) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc += a[l][c][k] * a[l2][c][k];
+            g[gi] = lcao_row16_sum(acc);
+          }
+          ++gi;
+        }
+    }
+    if (valid) {
+      if (sub < 10) {
+        float gv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) gv = (sub == i) ? g[i] : gv;
+        gram[p * 10 + sub] = gv;
+      }
+      const float* gt = gate + (int64_t)s * V + 4 * sub;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if ((64 * c + 4 * sub) < V) {
+          const f32x4 gg = *(const f32x4*)(gt + 64 * c);
+          f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            *(f32x4*)(Ag + (p * NL + l) * V + 64 * c + 4 * sub) = a[l][c] * gg;
+            bsum += a[l][c];
+          }
+          *(f32x4*)(B + p * V + 64 * c + 4 * sub) = bsum;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int lcao_pair_contract(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                                  const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
+                                  int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* Ag, float* B, float* gram,
+                                  void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (n_orb <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(Tf); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p);
+  LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(Ag); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(gram);
+  dim3 grid(lcao_blocks(n_edges, 16, 65536)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define PC_CASE(V_, NL_)                                                                                          \
+  if (V == V_ && n_l == NL_) {                                                                                    \
+    hipLaunchKernelGGL((k_pair_contract<V_, NL_>), grid, block, 0, st, Tf, rb, order, l_of_d, z, src_p, dst_p, gate, \
+                       n_edges, n_orb, zdim, Ag, B, gram);                                                        \
+    return lcao_launch_status();                                                                                  \
+  }
+#define PC_V(V_) PC_CASE(V_, 1) PC_CASE(V_, 2) PC_CASE(V_, 3) PC_CASE(V_, 4)
+  PC_V(128) PC_V(64) PC_V(32)
+#undef PC_V
+#undef PC_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}

@@ -115,12 +115,11 @@ class LCAOEmbedding(nn.Module):
         return x, cst
 
     @torch.no_grad()
-    def forward_species(self, z: Tensor, ctx: EdgeContext) -> tuple[Tensor, Tensor]:
-        """Eval-mode forward through per-species tables: every quantity above is a function of the atomic
-        number (x) or of the (z_s, z_t) pair (cst), so the MLPs run on max_z rows and one fused kernel writes
-        cst = bn(fe[z_t] * (1 + f_z([zc[z_s], zc[z_t]])))  (embed.py:246-249), 4*D*C bytes per edge."""
+    def species_tables(self, dev) -> dict:
+        """Eval-mode per-species tables (rows indexed by atomic number 0..max_z, row 0 unused): every quantity of
+        this module is a function of the atomic number (x) or of the (z_s, z_t) pair (cst), so the MLPs run on max_z
+        rows:  cst = bn(fe[z_t] * (1 + f_z([zc[z_s], zc[z_t]])))  (embed.py:246-249)."""
         assert not self.training
-        dev = z.device
         zz = torch.arange(1, self.max_z + 1, device=dev)
         z_embed = self.z_embed(zz)
         node_z, coeff_z = torch.split(z_embed, [self.emb_size, self.emb_size_coeff], dim=-1)
@@ -141,10 +140,30 @@ class LCAOEmbedding(nn.Module):
         bn = ce.bn
         scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias.detach() - bn.running_mean * scale
-        pad = lambda t: torch.cat([torch.zeros_like(t[:1]), t], dim=0).contiguous()  # tables indexed by z (1-based)
-        x = ops.gather_rows(pad(x_tab), z)
-        cst = ops.embed_coeffs(pad(FE), pad(U), pad(Vt), scale.contiguous(), shift.contiguous(), z, ctx.src_o, ctx.dst_o)
+        pad = lambda t: torch.cat([torch.zeros_like(t[:1]), t], dim=0).contiguous()
+        return dict(x=pad(x_tab), FE=pad(FE), U=pad(U), Vt=pad(Vt), scale=scale.contiguous(), shift=shift.contiguous())
+
+    @torch.no_grad()
+    def forward_species(self, z: Tensor, ctx: EdgeContext) -> tuple[Tensor, Tensor]:
+        """Eval-mode forward: node vectors by a row gather, cst (E, D, C) by ONE fused kernel (4*D*C bytes/edge)."""
+        t = self.species_tables(z.device)
+        x = ops.gather_rows(t["x"], z)
+        cst = ops.embed_coeffs(t["FE"], t["U"], t["Vt"], t["scale"], t["shift"], z, ctx.src_o, ctx.dst_o)
         return x, cst
+
+    @torch.no_grad()
+    def forward_pair_table(self, z: Tensor) -> tuple[Tensor, Tensor, int]:
+        """Species-pair form: x (N, H) and cst_pair ((max_z+1)^2, D, C) with row z_s*(max_z+1)+z_t —
+        the same kernel as forward_species run on the (max_z+1)^2 synthetic 'edges' (z_s, z_t)."""
+        dev = z.device
+        t = self.species_tables(dev)
+        x = ops.gather_rows(t["x"], z)
+        zd = self.max_z + 1
+        zfake = torch.arange(zd, device=dev)
+        src = torch.arange(zd, device=dev, dtype=torch.int32).repeat_interleave(zd)
+        dst = torch.arange(zd, device=dev, dtype=torch.int32).repeat(zd)
+        cst_pair = ops.embed_coeffs(t["FE"], t["U"], t["Vt"], t["scale"], t["shift"], zfake, src, dst)
+        return x, cst_pair, zd
 
 
 class LCAOInteraction(nn.Module):
@@ -205,7 +224,7 @@ class LCAOInteraction(nn.Module):
     def forward_fused(self, x: Tensor, cst: Tensor, valence_ed: Tensor | None, rb: Tensor, uvec: Tensor,
                       ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
                       trace: dict | None = None, exact_norm: bool = False, n_own: int | None = None,
-                      e_own: int | None = None) -> Tensor:
+                      e_own: int | None = None, pair: tuple | None = None) -> Tensor:
         """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1.
 
         n_own / e_own (sharded graphs, lcaonet_amd/shard.py): only the first n_own nodes are centres to update and
@@ -216,7 +235,7 @@ class LCAOInteraction(nn.Module):
         n_own = N if n_own is None else n_own
         e_own = ctx.n_edges if e_own is None else e_own
         if fused is None:
-            fused = self._fusable(cst.shape[-1])
+            fused = self._fusable(V if pair is not None else cst.shape[-1])
         wn, bn_ = self.node_weight.weight.detach(), self.node_weight.bias.detach()
         xs = ops.dense(x, wn[:V], bn_[:V])
         gate = ops.dense(x, wn[V:], bn_[V:], ops.ACT_SIGMOID)           # sigmoid(xk), gathered per triplet
@@ -226,7 +245,15 @@ class LCAOInteraction(nn.Module):
         out_ptr, in_ptr = ctx.out_ptr[: n_own + 1], ctx.in_ptr[: n_own + 1]
         src_own, dst_own = ctx.src_p[:e_own], ctx.dst_p[:e_own]
         # coefficient MLP + radial contraction (all local edges), then the three-body term (owned centres)
-        if fused:
+        if pair is not None:
+            # cst here is the ((max_z+1)^2, D, C) species-pair table: f_coeffs runs on ~1.4 k x D rows, and the
+            # per-edge work is a contraction of the cache-resident table with rb (no 2*D*(C*V+V*V) flop per edge)
+            z, zdim = pair
+            Tf = run_mlp(self.f_coeffs, cst)
+            Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
+            Bv = None
+            tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
+        elif fused:
             Ag, gram, B, Bv = ops.coeff_mlp_contract(
                 cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
                 self.f_coeffs[2].weight.detach(), n_l, self.add_valence,
@@ -448,7 +475,7 @@ class LCAONet(BaseMPNN):
     # --- forward ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
-                trace: dict | None = None, exact_norm: bool = False):
+                trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge"):
         """graph: PyG-Batch-like object with z, pos, edge_index [centre, neighbour], edge_shift, lattice and
         optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
         Inference only for now: no autograd graph is recorded (backward kernels: SURVEY.md §8f-3)."""
@@ -471,17 +498,30 @@ class LCAONet(BaseMPNN):
             graph = self.calc_3body_angles(self.get_triplets(graph))
 
         rb = self.rbf(dist)
-        if self.training:
+        pair = None
+        if cst_mode == "pair":
+            # cst_mode="pair": species-pair table instead of the per-edge (E, D, C) tensor.  Same
+            # outputs; valid when cst comes from this model's own embedding in eval mode.
+            if self.training or self.add_valence:
+                raise NotImplementedError("cst_mode='pair' needs eval mode and add_valence=False")
+            if self.emb_size_conv not in ops.FUSED_WIDTHS:
+                raise NotImplementedError(f"cst_mode='pair' is built for emb_size_conv in {ops.FUSED_WIDTHS}")
+            x, cst, zdim = self.emb_layer.forward_pair_table(z)
+            pair = (z, zdim)
+        elif cst_mode != "edge":
+            raise ValueError(f"cst_mode={cst_mode!r}: expected 'edge' or 'pair'")
+        elif self.training:
             x, cst = self.emb_layer(z, idx_s, idx_t)  # BatchNorm batch statistics: module path
         else:
             x, cst = self.emb_layer.forward_species(z, ctx)
         valence_ed = self.valence_mask.per_edge(z, idx_t) if self.add_valence else None
 
         if trace is not None:
-            trace.update(rb=rb, x0=x, cst=cst, order=ctx.order)
+            trace.update(rb=rb, x0=x, cst=cst, order=ctx.order)  # cst: pair table in cst_mode="pair"
         for i, inte in enumerate(self.int_layers):
             tr = {} if trace is not None else None
-            x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr, exact_norm)
+            x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr, exact_norm,
+                                   pair=pair)
             if trace is not None:
                 trace[f"x{i + 1}"] = x
                 trace[f"three_body_w{i + 1}"] = tr["three_body_w"]

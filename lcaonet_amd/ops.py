@@ -218,6 +218,21 @@ def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence,
     return (Ag if gated else A), gram, B, Bv
 
 
+def pair_contract(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_l, zdim):
+    """Tf ((zdim*zdim), D, V) pair table -> (Ag, gram, B) like coeff_mlp_contract(gate=...)."""
+    Tf, rb, gate = _f32(Tf, "Tf"), _f32(rb, "rb"), _f32(gate, "gate")
+    z = _i64(z)
+    E, D = rb.shape
+    V = Tf.shape[-1]
+    dev = rb.device
+    Ag = torch.empty(E, n_l, V, device=dev, dtype=torch.float32)
+    B = torch.empty(E, V, device=dev, dtype=torch.float32)
+    gram = torch.empty(E, 10, device=dev, dtype=torch.float32)
+    _call("lcao_pair_contract", _p(Tf), _p(rb), _p(order), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate), E, D, V,
+          n_l, zdim, _p(Ag), _p(B), _p(gram), _stream())
+    return Ag, gram, B
+
+
 def triplet_gemm(Ag, gram, uvec_p, in_ptr, in_pos, out_ptr, n_edges=None):
     """Centre nodes = the out_ptr.numel()-1 first nodes; writes tbw rows [0, out_ptr[-1]) (= n_edges when given)."""
     Ag, gram, uvec_p = _f32(Ag), _f32(gram), _f32(uvec_p)

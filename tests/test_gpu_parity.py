@@ -351,3 +351,27 @@ def test_sharded_forward_hip_matches_unsharded(dev, world, cells):
         assert calls[0] == kw["n_interaction"] - 1          # L-1 exchanges
         total = total + part
     assert relerr(total, full) <= 2e-6
+
+
+@pytest.mark.parametrize("width,heads", [(128, 64), (64, 64), (32, 16), (48, 16)])
+def test_pair_table_mode_vs_oracle_and_edge_mode(dev, width, heads):
+    """cst_mode='pair' (SURVEY.md §8f-2): identical outputs from the species-pair table."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=heads, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0, max_z=36)
+    m, sd = _random_model(dev, 300 + width, **kw)
+    g = random_periodic_cells(3, 14, 6.2, 0.99 * 5.0, seed=width + 1)
+    if width == 48:  # not one of the built widths: refuses loudly instead of silently switching path
+        with pytest.raises(NotImplementedError):
+            m(g.to(dev), cst_mode="pair")
+        return
+    want, wtr = _oracle_run(sd, kw, g.to_dict())
+    tr = {}
+    got = m(g.to(dev), cst_mode="pair", trace=tr)
+    order = tr["order"].long().cpu()
+    assert relerr(tr["three_body_w1"], wtr["three_body_w1"][order]) <= TOL
+    assert relerr(tr["x2"], wtr["x2"]) <= TOL
+    assert relerr(got, want) <= TOL
+    assert relerr(got, m(g.to(dev))) <= 2e-6
+    # the pair table really is what the per-edge tensor holds
+    z = g["z"]; idx_s, idx_t = g["edge_index"]
+    assert relerr(tr["cst"][(z[idx_s] * 37 + z[idx_t]).to(dev)][:64], wtr["cst"][:64]) <= TOL
