@@ -67,6 +67,16 @@ int lcao_sph_basis(const float* costheta, int64_t n, int n_orb, const int32_t* l
 int lcao_triplet_angles(const float* uvec, const int64_t* e_st, const int64_t* e_ks, int64_t n_trip, float* cosv,
                         void* stream);
 
+/* a2 / SURVEY 8f-1  index structures of one forward, built on the device without a host sync (replaces
+ * LCAONet.get_triplets, lcaonet/model/lcaonet.py:439-486, and its torch_sparse sort / row-select):
+ *   order, src_p, dst_p (E): edges stably sorted by centre node;  out_ptr (N+1);  in_pos (E), in_ptr (N+1): for each
+ *   node s the p-indices of the edges k->s ordered by (k, caller's edge id);  src_o, dst_o (E): idx_s / idx_t as int32.
+ * workspace: device, >= lcao_build_csr_workspace_bytes(E, N) bytes. */
+size_t lcao_build_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
+int lcao_build_csr(const int64_t* idx_s, const int64_t* idx_t, int64_t n_edges, int64_t n_nodes, int32_t* order,
+                   int32_t* src_p, int32_t* dst_p, int32_t* out_ptr, int32_t* in_ptr, int32_t* in_pos, int32_t* src_o,
+                   int32_t* dst_o, void* workspace, size_t ws_bytes, void* stream);
+
 /* Dense layers on the path (lcaonet/nn/base.py:71-81 used at lcaonet.py:167,170,192,209,214,290,305):
  * Y[m, n] = act( sum_k X[m,k] * W[n,k] + bias[n] ) + residual[m,n];  bias / residual nullable. */
 int lcao_dense(const float* X, int64_t ldx, const float* W, const float* bias, const float* residual, int64_t ldr,

@@ -21,6 +21,8 @@ SIGNATURES = {
     "lcao_radial_basis": [P, L, I, P, I, I, F, P, P],
     "lcao_sph_basis": [P, L, I, P, P, P],
     "lcao_triplet_angles": [P, P, P, L, P, P],
+    "lcao_build_csr_workspace_bytes": [L, L],
+    "lcao_build_csr": [P, P, L, L, P, P, P, P, P, P, P, P, P, c_size_t, P],
     "lcao_dense": [P, L, P, P, P, L, P, L, L, I, I, I, P],
     "lcao_segment_sum": [P, P, P, L, I, P, P],
     "lcao_gather_rows": [P, P, L, I, P, P],
@@ -39,7 +41,8 @@ SIGNATURES = {
     "lcao_lds_bytes_coeff_mlp": [I, I, I],
     "lcao_debug_set_clock_probe": [P],
 }
-_RESTYPES = {"lcao_error_string": c_char_p, "lcao_lds_bytes_coeff_mlp": c_size_t, "lcao_debug_set_clock_probe": None}
+_RESTYPES = {"lcao_error_string": c_char_p, "lcao_lds_bytes_coeff_mlp": c_size_t,
+             "lcao_build_csr_workspace_bytes": c_size_t, "lcao_debug_set_clock_probe": None}
 
 _lib = None
 

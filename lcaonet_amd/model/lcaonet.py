@@ -71,16 +71,8 @@ class EdgeContext:
         E = idx_s.numel()
         if E >= 2**31 or n_nodes >= 2**31:
             raise ValueError("graph too large for int32 indexing on one GPU")
-        order = torch.argsort(idx_s, stable=True)
-        src_sorted = idx_s[order]
-        dst_sorted = idx_t[order]
-        in_pos = torch.argsort(dst_sorted, stable=True)
-        return EdgeContext(
-            n_nodes=n_nodes, n_edges=E,
-            order=order.to(torch.int32), src_p=src_sorted.to(torch.int32), dst_p=dst_sorted.to(torch.int32),
-            out_ptr=csr_ptr(src_sorted, n_nodes), in_ptr=csr_ptr(dst_sorted[in_pos], n_nodes),
-            in_pos=in_pos.to(torch.int32), src_o=idx_s.to(torch.int32), dst_o=idx_t.to(torch.int32),
-        )
+        c = ops.build_csr(idx_s, idx_t, n_nodes)   # lcao_build_csr: two stable radix sorts + lower bounds, no sync
+        return EdgeContext(n_nodes=n_nodes, n_edges=E, **c)
 
 
 class LCAOEmbedding(nn.Module):

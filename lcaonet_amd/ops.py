@@ -84,6 +84,22 @@ def _call(name: str, *args) -> None:
     _PROFILE.setdefault(name, []).append((a, b))
 
 
+def build_csr(idx_s: Tensor, idx_t: Tensor, n_nodes: int) -> dict:
+    """All int32 index structures of one forward in one C-ABI call (no host sync, no torch sort)."""
+    idx_s, idx_t = _i64(idx_s, "edge_index[0]"), _i64(idx_t, "edge_index[1]")
+    E, dev = idx_s.numel(), idx_s.device
+    i32 = lambda n: torch.empty(n, device=dev, dtype=torch.int32)
+    out = dict(order=i32(E), src_p=i32(E), dst_p=i32(E), out_ptr=i32(n_nodes + 1), in_ptr=i32(n_nodes + 1),
+               in_pos=i32(E), src_o=i32(E), dst_o=i32(E))
+    lib = _lib.load()
+    ws_bytes = int(lib.lcao_build_csr_workspace_bytes(E, n_nodes))
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    _call("lcao_build_csr", _p(idx_s), _p(idx_t), E, n_nodes, _p(out["order"]), _p(out["src_p"]), _p(out["dst_p"]),
+          _p(out["out_ptr"]), _p(out["in_ptr"]), _p(out["in_pos"]), _p(out["src_o"]), _p(out["dst_o"]), _p(ws), ws_bytes,
+          _stream())
+    return out
+
+
 def edge_geometry(pos, idx_s, idx_t, shift, lattice, batch):
     pos, shift, lattice = _f32(pos, "pos"), _f32(shift, "edge_shift"), _f32(lattice, "lattice")
     idx_s, idx_t = _i64(idx_s), _i64(idx_t)

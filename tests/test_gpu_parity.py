@@ -375,3 +375,23 @@ def test_pair_table_mode_vs_oracle_and_edge_mode(dev, width, heads):
     # the pair table really is what the per-edge tensor holds
     z = g["z"]; idx_s, idx_t = g["edge_index"]
     assert relerr(tr["cst"][(z[idx_s] * 37 + z[idx_t]).to(dev)][:64], wtr["cst"][:64]) <= TOL
+
+
+def test_build_csr_kernel(dev):
+    """lcao_build_csr against a host construction: stable order by centre, in-edge lists ordered by
+    (source, caller's edge id), pointer arrays; unsorted input, isolated nodes, duplicate edges, empty graph."""
+    from lcaonet_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for N, E in ((50, 400), (7, 0), (1000, 20000), (3, 8)):
+        idx_s = torch.randint(0, max(N - 3, 1), (E,), generator=g)      # the last nodes stay isolated
+        idx_t = torch.randint(0, max(N - 3, 1), (E,), generator=g)
+        c = ops.build_csr(idx_s.to(dev), idx_t.to(dev), N)
+        order = torch.argsort(idx_s, stable=True)
+        assert c["order"].cpu().tolist() == order.tolist()
+        assert c["src_p"].cpu().tolist() == idx_s[order].tolist() and c["dst_p"].cpu().tolist() == idx_t[order].tolist()
+        in_pos = torch.argsort(idx_t[order], stable=True)
+        assert c["in_pos"].cpu().tolist() == in_pos.tolist()
+        cnt_s, cnt_t = torch.bincount(idx_s, minlength=N), torch.bincount(idx_t, minlength=N)
+        assert c["out_ptr"].cpu().tolist() == [0] + torch.cumsum(cnt_s, 0).tolist()
+        assert c["in_ptr"].cpu().tolist() == [0] + torch.cumsum(cnt_t, 0).tolist()
+        assert c["src_o"].cpu().tolist() == idx_s.tolist() and c["dst_o"].cpu().tolist() == idx_t.tolist()
