@@ -726,7 +726,9 @@ __device__ __forceinline__ float triplet_weight(float ux, float uy, float uz, fl
 #pragma unroll
     for (int l2 = l + 1; l2 < NL; ++l2) n2 += 2.0f * (y[l] * y[l2]) * G[gram_idx(l, l2)];
   }
-  const float inv = 1.0f / fmaxf(sqrtf(fmaxf(n2, 0.f)), 1e-12f);
+  // 1 / max(sqrt(n2), 1e-12) = rsqrt(max(n2, 1e-24)): one v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide
+  // sequences (~40 VALU per weight, more than the MFMAs each weight feeds)
+  const float inv = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));
   const float yq = quarter == 0 ? y[0] : (quarter == 1 ? y[1] : (quarter == 2 ? y[2] : y[3]));
   return ok ? yq * inv : 0.f;
 }
@@ -743,9 +745,31 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, quarter = lane >> 4;
   const bool frag_ok0 = quarter < NL;
+
+  // One step = one in-edge q.  Everything a step needs arrives through the VECTOR memory pipe, PD steps ahead:
+  //   F[h]: this lane's 16-B pieces of Ag[q, quarter, :]          (2 x global_load_dwordx4)
+  //   R   : lane i < 3 holds u_q[i], lane 3 + i holds gram[q, i]  (1 x global_load_dword, then v_readlane)
+  // VMEM returns in order, so the compiler's counted vmcnt leaves the later steps in flight while step j is consumed;
+  // scalar (SMEM) loads would force lgkmcnt(0) on every use and sat on the critical path of each step.
+  auto load_step = [&](f32x4v(&F)[HG], float& R, int q) {
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+      F[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      if (frag_ok0 && (64 * h + 4 * n) < V) F[h] = *(const f32x4v*)(Ag + ((int64_t)q * NL + quarter) * V + 64 * h + 4 * n);
+    }
+    R = 0.f;
+    if (lane < 3) R = uvec_p[3 * (int64_t)q + lane];
+    else if (lane < 13) R = gram[10 * (int64_t)q + (lane - 3)];
+  };
+
+  // PD steps stay in flight per wave (PD x 1.5 KB at V=128, n_l=3): with 3 waves per SIMD that is ~100 KB of loads in
+  // flight per CU, what a random row gather needs to approach the HBM rate (one-step-ahead prefetch held 30 KB in
+  // flight and stalled 59 % of wave time in s_waitcnt).  Slots are indexed statically (the step loop is unrolled by PD).
+  constexpr int PD = 6;
   for (int s = blockIdx.x * 4 + wave; s < n_nodes; s += gridDim.x * 4) {
     const int p0 = out_ptr[s], p1 = out_ptr[s + 1];
-    const int j0 = in_ptr[s], j1 = in_ptr[s + 1];
+    const int j0 = in_ptr[s];
+    const int nin = in_ptr[s + 1] - j0;
     for (int pb = p0; pb < p1; pb += 32) {
       const int pA = pb + n, pB = pb + 16 + n;
       const bool vA = pA < p1, vB = pB < p1;
@@ -762,45 +786,56 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) acc[t][h][jj] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-      // software pipeline: the A fragments of in-edge j+1 are in flight while in-edge j is multiplied
-      f32x4v cur[HG], nxt[HG];
-      int qe = (j0 < j1) ? in_pos[j0] : 0;
+      for (int jc = 0; jc < nin; jc += 64) {   // in-edge ids of this node, 64 at a time: lane i holds in_pos[j0+jc+i]
+        const int cn = min(64, nin - jc);
+        const int idv = in_pos[j0 + jc + min(lane, cn - 1)];
+        f32x4v F[PD][HG];
+        float R[PD];
+        int Q[PD];
 #pragma unroll
-      for (int h = 0; h < HG; ++h) {
-        cur[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        if (j0 < j1 && frag_ok0 && (64 * h + 4 * n) < V)
-          cur[h] = *(const f32x4v*)(Ag + ((int64_t)qe * NL + quarter) * V + 64 * h + 4 * n);
-      }
-      for (int j = j0; j < j1; ++j) {
-        const int qn = (j + 1 < j1) ? in_pos[j + 1] : qe;
-#pragma unroll
-        for (int h = 0; h < HG; ++h) {
-          nxt[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
-          if (j + 1 < j1 && frag_ok0 && (64 * h + 4 * n) < V)
-            nxt[h] = *(const f32x4v*)(Ag + ((int64_t)qn * NL + quarter) * V + 64 * h + 4 * n);
+        for (int i = 0; i < PD; ++i) {
+          Q[i] = __builtin_amdgcn_readlane(idv, min(i, cn - 1));
+          if (i < cn) load_step(F[i], R[i], Q[i]);
         }
-        const float* uq = uvec_p + 3 * (int64_t)qe;
-        const float qx = uq[0], qy = uq[1], qz = uq[2];
-        float G[10];
-        const float* gp = gram + (int64_t)qe * 10;
+        for (int jb = 0; jb < cn; jb += PD) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) G[i] = gp[i];
-        // lcaonet.py:470 drops only the triplet whose two edges coincide (q == p); the back-triplet stays
-        const float wA = triplet_weight<NL>(uax, uay, uaz, qx, qy, qz, G, quarter, vA && qe != pA);
+          for (int i = 0; i < PD; ++i) {
+            const int j = jb + i;
+            if (j < cn) {  // wave-uniform
+              const int q0 = Q[i];
+              const int r0i = __float_as_int(R[i]);  // readlane moves raw 32-bit lanes
+              const float qx = __int_as_float(__builtin_amdgcn_readlane(r0i, 0)),
+                          qy = __int_as_float(__builtin_amdgcn_readlane(r0i, 1)),
+                          qz = __int_as_float(__builtin_amdgcn_readlane(r0i, 2));
+              float G[10];
 #pragma unroll
-        for (int h = 0; h < HG; ++h)
+              for (int k = 0; k < 10; ++k) G[k] = 0.f;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[0][h][jj] = MFMA16(cur[h][jj], wA, acc[0][h][jj]);
-        if (two) {
-          const float wB = triplet_weight<NL>(ubx, uby, ubz, qx, qy, qz, G, quarter, vB && qe != pB);
+              for (int l = 0; l < NL; ++l)
 #pragma unroll
-          for (int h = 0; h < HG; ++h)
+                for (int l2 = l; l2 < NL; ++l2)
+                  G[gram_idx(l, l2)] = __int_as_float(__builtin_amdgcn_readlane(r0i, 3 + gram_idx(l, l2)));
+              // lcaonet.py:470 drops only the triplet whose two edges coincide (q == p); the back-triplet stays
+              const float wA = triplet_weight<NL>(uax, uay, uaz, qx, qy, qz, G, quarter, vA && q0 != pA);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[1][h][jj] = MFMA16(cur[h][jj], wB, acc[1][h][jj]);
+              for (int h = 0; h < HG; ++h)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[0][h][jj] = MFMA16(F[i][h][jj], wA, acc[0][h][jj]);
+              if (two) {
+                const float wB = triplet_weight<NL>(ubx, uby, ubz, qx, qy, qz, G, quarter, vB && q0 != pB);
+#pragma unroll
+                for (int h = 0; h < HG; ++h)
+#pragma unroll
+                  for (int jj = 0; jj < 4; ++jj) acc[1][h][jj] = MFMA16(F[i][h][jj], wB, acc[1][h][jj]);
+              }
+              // refill this slot with step j + PD
+              if (j + PD < cn) {
+                Q[i] = __builtin_amdgcn_readlane(idv, j + PD);
+                load_step(F[i], R[i], Q[i]);
+              }
+            }
+          }
         }
-#pragma unroll
-        for (int h = 0; h < HG; ++h) cur[h] = nxt[h];
-        qe = qn;
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
