@@ -31,6 +31,9 @@ WORKLOADS = {
     # name: (generator kwargs, model kwargs)
     "cfg2": (dict(n_cells=1000, n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, max_z=36),
              dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=5.0)),
+    # one rank's share (1/8) of BASELINE config 4: a 63^3 = 250 047-atom periodic crystal, cutoff 6.0, 32 nearest neighbours
+    "cfg4-1of8": (dict(crystal=True, n_side=63, a=3.2, sigma=0.05, cutoff_graph=5.94, max_neighbors=32, max_z=36),
+                  dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=6.0)),
     "cfg2-small": (dict(n_cells=64, n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, max_z=36),
                    dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=5.0)),
 }
@@ -127,7 +130,13 @@ def main():
 
     gen_kw, model_kw = WORKLOADS[args.workload]
     model = build_model(model_kw, 1234, dev)                      # identical weights on every rank
-    batch = jittered_cubic_cells(seed=1234 + rank, device=dev, **gen_kw)  # this rank's own crystals
+    if gen_kw.get("crystal"):
+        from lcaonet_amd.data.synthetic import jittered_cubic_crystal
+        ck = {k: v for k, v in gen_kw.items() if k != "crystal"}
+        batch = jittered_cubic_crystal(seed=1234 + rank, device=dev, **ck)
+        gen_kw = dict(gen_kw, n_cells=1)
+    else:
+        batch = jittered_cubic_cells(seed=1234 + rank, device=dev, **gen_kw)  # this rank's own crystals
     E = int(batch["edge_index"].shape[1])
     N = int(batch["z"].numel())
     fused = None if args.fused < 0 else bool(args.fused)

@@ -77,6 +77,20 @@ int lcao_build_csr(const int64_t* idx_s, const int64_t* idx_t, int64_t n_edges, 
                    int32_t* src_p, int32_t* dst_p, int32_t* out_ptr, int32_t* in_ptr, int32_t* in_pos, int32_t* src_o,
                    int32_t* dst_o, void* workspace, size_t ws_bytes, void* stream);
 
+/* SURVEY 8f-1  periodic cell-list neighbour search on the device: what lcaonet/data/convert.py:124-129 obtains from
+ * ase.neighbor_list("ijdS") on the CPU.  `graphs`: one 32-word record per graph {lattice[9], inverse[9], bins[3],
+ * reach[3], pbc[3], bin_base, pad[4]} (lcaonet_amd/data/neighbors.py builds it).  Edge convention of the reference:
+ * vec = pos[dst] - pos[src] + shift @ lattice.  The caller sorts the candidates per centre by distance and truncates
+ * to max_neighbors (convert.py:135-148). */
+size_t lcao_nl_workspace_bytes(int64_t n_atoms);
+int lcao_nl_bin_sort(const float* pos, const int64_t* batch /*nullable*/, const void* graphs, int64_t n_atoms,
+                     int64_t n_bins, float* wpos, int32_t* wrap, int32_t* atom_of, int32_t* bin_ptr, void* workspace,
+                     size_t ws_bytes, void* stream);
+int lcao_nl_search(const float* wpos, const int32_t* wrap, const int64_t* batch, const void* graphs,
+                   const int32_t* atom_of, const int32_t* bin_ptr, int64_t n_atoms, float cutoff, int fill,
+                   int32_t* count, const int64_t* offset, int64_t* e_src, int64_t* e_dst, float* e_shift, float* e_dist,
+                   void* stream);
+
 /* Dense layers on the path (lcaonet/nn/base.py:71-81 used at lcaonet.py:167,170,192,209,214,290,305):
  * Y[m, n] = act( sum_k X[m,k] * W[n,k] + bias[n] ) + residual[m,n];  bias / residual nullable. */
 int lcao_dense(const float* X, int64_t ldx, const float* W, const float* bias, const float* residual, int64_t ldr,

@@ -23,6 +23,9 @@ SIGNATURES = {
     "lcao_triplet_angles": [P, P, P, L, P, P],
     "lcao_build_csr_workspace_bytes": [L, L],
     "lcao_build_csr": [P, P, L, L, P, P, P, P, P, P, P, P, P, c_size_t, P],
+    "lcao_nl_workspace_bytes": [L],
+    "lcao_nl_bin_sort": [P, P, P, L, L, P, P, P, P, P, c_size_t, P],
+    "lcao_nl_search": [P, P, P, P, P, P, L, F, I, P, P, P, P, P, P, P],
     "lcao_dense": [P, L, P, P, P, L, P, L, L, I, I, I, P],
     "lcao_segment_sum": [P, P, P, L, I, P, P],
     "lcao_gather_rows": [P, P, L, I, P, P],
@@ -42,7 +45,7 @@ SIGNATURES = {
     "lcao_debug_set_clock_probe": [P],
 }
 _RESTYPES = {"lcao_error_string": c_char_p, "lcao_lds_bytes_coeff_mlp": c_size_t,
-             "lcao_build_csr_workspace_bytes": c_size_t, "lcao_debug_set_clock_probe": None}
+             "lcao_build_csr_workspace_bytes": c_size_t, "lcao_nl_workspace_bytes": c_size_t, "lcao_debug_set_clock_probe": None}
 
 _lib = None
 

@@ -268,6 +268,13 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
 #if LCAO_ABL & 16
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef LCAO_STAGGER
+  // one-time stagger of the second wave of every SIMD (waves 4-7) by LCAO_STAGGER x ~8k cycles
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
+#pragma unroll
+    for (int i = 0; i < LCAO_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const int64_t first_dynamic = (int64_t)gridDim.x * WAVES;
   int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
   for (; tile < n_tiles;) {

@@ -151,3 +151,22 @@ def reference_fixture_graph(device="cpu"):
         edge_shift=shift,
         lattice=torch.eye(3).unsqueeze(0) * 15.0,
     ).to(device)
+
+
+def jittered_cubic_crystal(n_side: int, a: float = 3.2, sigma: float = 0.05, cutoff_graph: float = 5.94,
+                           max_neighbors: int | None = 32, max_z: int = 36, seed: int = 1234, device="cuda",
+                           dtype=torch.float32) -> Batch:
+    """BASELINE config 4 shape: ONE periodic crystal of n_side^3 atoms (jittered simple cubic), neighbour list built
+    on the GPU by the cell-list kernels (data/neighbors.py), truncated to the `max_neighbors` nearest per centre as
+    the reference's converter does (convert.py:40,145).  n_side = 126 gives the 2 M-atom crystal of config 4; atoms are
+    in x-major grid order, so contiguous node ranges are spatial slabs (what shard.make_plans partitions by)."""
+    from .neighbors import make_graph
+
+    g = torch.Generator().manual_seed(seed)
+    n = n_side**3
+    r = torch.arange(n_side, dtype=torch.float64)
+    grid = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1).reshape(n, 3) * a
+    pos = (grid + torch.randn(n, 3, generator=g, dtype=torch.float64) * (sigma * a)).to(dtype).to(device)
+    z = torch.randint(1, max_z + 1, (n,), generator=g).to(device)
+    lattice = (torch.eye(3, dtype=dtype) * (n_side * a)).unsqueeze(0).to(device)
+    return make_graph(z, pos, lattice, cutoff_graph, None, None, max_neighbors)

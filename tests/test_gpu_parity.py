@@ -136,6 +136,14 @@ def test_scatter_semantics(dev):
     cnt = torch.bincount(idx, minlength=7).clamp(min=1).unsqueeze(1)
     assert relerr(scatter(src.to(dev), idx.to(dev), dim=0, dim_size=7, reduce="mean"), want / cnt) <= 1e-6
     assert scatter(src.to(dev), idx.to(dev)).shape[0] == int(idx.max()) + 1
+    # few long segments take the two-level reduction (per-graph sums over 10^5 atoms): same answer
+    big = torch.rand(50000, 3, generator=g)
+    bidx = (torch.rand(50000, generator=g) < 0.7).long() * 2          # segments 0 and 2 long, 1 and 3 empty
+    got = scatter(big.to(dev), bidx.to(dev), dim=0, dim_size=4)
+    want = torch.zeros(4, 3, dtype=torch.float64).index_add_(0, bidx, big.double())
+    assert relerr(got, want) <= 1e-6 and float(got[1].abs().max()) == 0.0 and float(got[3].abs().max()) == 0.0
+    got1 = scatter(big.to(dev), torch.zeros(50000, dtype=torch.long, device=dev), dim=0, dim_size=1)
+    assert relerr(got1, big.double().sum(0, keepdim=True)) <= 1e-6
 
 
 def test_geometry_and_triplets(golden_loader, dev):
@@ -395,3 +403,98 @@ def test_build_csr_kernel(dev):
         assert c["out_ptr"].cpu().tolist() == [0] + torch.cumsum(cnt_s, 0).tolist()
         assert c["in_ptr"].cpu().tolist() == [0] + torch.cumsum(cnt_t, 0).tolist()
         assert c["src_o"].cpu().tolist() == idx_s.tolist() and c["dst_o"].cpu().tolist() == idx_t.tolist()
+
+
+def _brute_force_edges(pos, lat, cutoff, pbc=(True, True, True), n_img=3):
+    """All (i, j, S) with |pos[j] - pos[i] + S @ lat| <= cutoff, excluding (i, i, 0): O(n^2 images) host reference."""
+    rng = [torch.arange(-n_img, n_img + 1) if p else torch.zeros(1, dtype=torch.long) for p in pbc]
+    S = torch.stack(torch.meshgrid(*rng, indexing="ij"), -1).reshape(-1, 3).double()
+    off = S @ lat.double()
+    vec = pos.double()[None, :, None, :] - pos.double()[:, None, None, :] + off[None, None, :, :]
+    d = vec.norm(dim=-1)
+    m = d <= cutoff
+    i, j, s = m.nonzero(as_tuple=True)
+    keep = ~((i == j) & (S[s].abs().sum(1) == 0))
+    return i[keep], j[keep], S[s][keep], d[i, j, s][keep]
+
+
+@pytest.mark.parametrize("case", ["cubic", "triclinic_small", "unwrapped", "molecule", "slab"])
+def test_neighbor_list_kernel_vs_brute_force(dev, case):
+    """lcao_nl_*  against a brute-force image sum: general cells, cells smaller than the cutoff
+    (several images, self-images), positions outside the cell, non-periodic and mixed periodicity."""
+    from lcaonet_amd.data.neighbors import neighbor_list
+    g = torch.Generator().manual_seed(7)
+    cutoff, pbc = 3.0, (True, True, True)
+    if case == "cubic":
+        lat = torch.eye(3) * 9.5
+        pos = torch.rand(80, 3, generator=g) * 9.5
+    elif case == "triclinic_small":
+        lat = torch.tensor([[2.6, 0.0, 0.0], [0.9, 2.4, 0.0], [0.4, -0.7, 2.9]])
+        pos = torch.rand(5, 3, generator=g) @ lat
+    elif case == "unwrapped":
+        lat = torch.tensor([[7.0, 0.5, 0.0], [0.0, 6.5, 0.3], [0.2, 0.0, 8.0]])
+        pos = (torch.rand(40, 3, generator=g) * 3 - 1) @ lat      # fractional coordinates in [-1, 2)
+    elif case == "molecule":
+        lat, pbc = torch.eye(3) * 50.0, (False, False, False)
+        pos = torch.rand(30, 3, generator=g) * 6.0 - 1.0             # partly outside the dummy box
+    else:
+        lat, pbc = torch.tensor([[6.0, 0, 0], [0, 6.5, 0], [0, 0, 20.0]]), (True, True, False)
+        pos = torch.rand(50, 3, generator=g) * torch.tensor([6.0, 6.5, 7.0])
+    wi, wj, wS, wd = _brute_force_edges(pos, lat, cutoff, pbc)
+    ei, shift, dist = neighbor_list(pos.to(dev), lat.unsqueeze(0).to(dev), cutoff,
+                                    pbc=torch.tensor([pbc]), max_neighbors=None)
+    ei, shift, dist = ei.cpu(), shift.cpu(), dist.cpu()
+    assert ei.shape[1] == wi.numel() > 0
+    key = lambda i, j, S: sorted(zip(i.tolist(), j.tolist(), map(tuple, S.round().int().tolist())))
+    assert key(ei[0], ei[1], shift) == key(wi, wj, wS)
+    vec = pos[ei[1]] - pos[ei[0]] + shift @ lat
+    assert float((vec.norm(dim=1) - dist).abs().max()) < 1e-4 and float(dist.max()) <= cutoff + 1e-5
+    assert bool((ei[0][1:] >= ei[0][:-1]).all())                     # grouped by centre ...
+    same = ei[0][1:] == ei[0][:-1]
+    assert bool((dist[1:][same] >= dist[:-1][same] - 1e-6).all())    # ... ordered by distance
+    # max_neighbors truncation keeps the nearest ones (convert.py:145)
+    ei2, _, d2 = neighbor_list(pos.to(dev), lat.unsqueeze(0).to(dev), cutoff, pbc=torch.tensor([pbc]), max_neighbors=4)
+    cnt = torch.bincount(ei2[0].cpu(), minlength=pos.shape[0])
+    assert int(cnt.max()) <= 4
+    full_cnt = torch.bincount(ei[0], minlength=pos.shape[0])
+    assert torch.equal(cnt, full_cnt.clamp(max=4))
+
+
+def test_neighbor_list_batched_and_model_roundtrip(dev):
+    """A batch of cells built on the GPU gives the same model output as the host-built graph."""
+    from lcaonet_amd.data.neighbors import make_graph
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=4.0)
+    m, _ = _random_model(dev, 5, **kw)
+    host = random_periodic_cells(5, 14, 6.5, 0.99 * 4.0, seed=2).to(dev)
+    built = make_graph(host["z"], host["pos"], host["lattice"], 0.99 * 4.0, batch=host["batch"], max_neighbors=None)
+    assert built["edge_index"].shape == host["edge_index"].shape
+    assert relerr(m(built), m(host)) <= 2e-6
+    # no neighbour anywhere -> fully linked fallback (data/utils.py:10-20)
+    far = make_graph(host["z"][:4], torch.eye(3, device=dev)[[0, 1, 2, 0]] * torch.tensor([[10.], [20.], [30.], [40.]], device=dev),
+                     torch.eye(3, device=dev).unsqueeze(0) * 200.0, 2.0)
+    assert far["edge_index"].shape[1] == 12 and float(far["edge_shift"].abs().max()) == 0.0
+
+
+def test_single_crystal_sharded_in_slabs(dev):
+    """BASELINE config 4 shape at 1/145 scale: one 24^3 = 13 824-atom periodic crystal (cutoff 6.0, 32 nearest
+    neighbours) built on the GPU, partitioned into 4 spatial slabs; each slab's result equals the unsharded forward."""
+    from lcaonet_amd import shard
+    from lcaonet_amd.data.synthetic import jittered_cubic_crystal
+    kw = dict(emb_size=64, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=6.0)
+    m, _ = _random_model(dev, 33, **kw)
+    g = jittered_cubic_crystal(24, cutoff_graph=0.99 * 6.0, max_neighbors=32, device=dev)
+    N, E = g["z"].numel(), g["edge_index"].shape[1]
+    assert N == 13824 and 24 * N < E <= 32 * N        # shells at a, sqrt2 a, sqrt3 a (6+12+8); 2a = 6.4 is outside 5.94
+    tr = {}
+    full = m(g, trace=tr)
+    plans = shard.make_plans(g, 4)
+    halo = [p.n_ghost / p.n_own for p in plans]
+    assert max(halo) < 0.8                             # slabs of 6 layers, 2 layers of halo on each side
+    total = torch.zeros_like(full)
+    for plan in plans:
+        def exchange_fn(x_own, plan=plan):
+            assert relerr(x_own, tr["x1"][plan.owned_global]) <= 2e-6
+            return tr["x1"][plan.ghost_global].contiguous()
+        total = total + m.forward_sharded(plan, exchange_fn=exchange_fn, reduce_fn=lambda p: p)
+    assert relerr(total, full) <= 5e-6
