@@ -170,3 +170,25 @@ def jittered_cubic_crystal(n_side: int, a: float = 3.2, sigma: float = 0.05, cut
     z = torch.randint(1, max_z + 1, (n,), generator=g).to(device)
     lattice = (torch.eye(3, dtype=dtype) * (n_side * a)).unsqueeze(0).to(device)
     return make_graph(z, pos, lattice, cutoff_graph, None, None, max_neighbors)
+
+
+def random_molecule_batch(n_mol: int, min_atoms: int = 3, max_atoms: int = 29, species=(1, 6, 7, 8, 9),
+                          cutoff_graph: float = 5.94, density: float = 0.08, seed: int = 1234, device="cuda",
+                          max_neighbors: int | None = None, dtype=torch.float32) -> Batch:
+    """BASELINE config 5 shape (QM9-like): `n_mol` non-periodic molecules with U{min_atoms..max_atoms} atoms each,
+    z drawn from `species`, atoms uniform in a cube sized for `density` atoms/A^3 (near-complete graphs at cutoff 6),
+    50 A dummy lattice and zero shifts as the reference's converter writes for molecules."""
+    from .neighbors import make_graph
+
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.randint(min_atoms, max_atoms + 1, (n_mol,), generator=g)
+    batch = torch.repeat_interleave(torch.arange(n_mol), sizes)
+    n = int(sizes.sum())
+    extent = (sizes.double() / density) ** (1.0 / 3.0)
+    pos = torch.rand(n, 3, generator=g, dtype=torch.float64) * extent[batch].unsqueeze(1)
+    sp = torch.tensor(species)
+    z = sp[torch.randint(0, len(species), (n,), generator=g)]
+    lattice = (torch.eye(3, dtype=dtype) * 50.0).unsqueeze(0).repeat(n_mol, 1, 1)
+    pbc = torch.zeros(n_mol, 3, dtype=torch.bool)
+    return make_graph(z.to(device), pos.to(dtype).to(device), lattice.to(device), cutoff_graph, batch.to(device),
+                      pbc.to(device), max_neighbors)
