@@ -188,6 +188,28 @@ int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, co
                            const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
                            float* msg, void* stream);
 
+/* ---- activation-gradient kernels for autograd forces at inference (lcaonet/model/lcaonet.py:310-317).
+ * g_X = dE/dX.  Dense layers are differentiated by lcao_dense on transposed weights; see csrc/lcao_backward.hip. ---- */
+int lcao_act_bwd(const float* g, const float* pre, int64_t n, int act, float* out, void* stream);
+int lcao_pair_pre(const float* Ps, const float* Pt, const int32_t* src_p, const int32_t* dst_p, int64_t n_edges, int V,
+                  float* pre1, void* stream);
+int lcao_message_bwd(const float* g_agg, const int32_t* src_p, const float* bw, const float* pre2, int64_t n_edges, int V,
+                     float* g_bw, float* g_pre2, void* stream);
+int lcao_combine_bwd(const float* g_lw, const float* B, const float* ft, int64_t n_edges, int V, float* g_B, float* g_ft,
+                     void* stream);
+/* three-body backward: g_tbw -> g_Ag, g_gram (per in-edge), g_uq / g_up (dE/d unit vector as in-edge / out-edge);
+ * tbase[s] = offset of node s in the (sum_s m_in*m_out) float scratch `gc_scratch` */
+int lcao_triplet_bwd(const float* g_tbw, const float* Ag, const float* gram, const float* uvec_p, const int32_t* src_p,
+                     const int32_t* dst_p, const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr,
+                     const int64_t* tbase, int64_t n_edges, int64_t e_own, int n_own, int64_t n_in_total, int V, int n_l,
+                     float* g_Ag, float* g_gram, float* g_uq, float* g_up, float* gc_scratch, void* stream);
+int lcao_pair_contract_bwd(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d, const int64_t* z,
+                           const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* g_Ag,
+                           const float* g_B, const float* g_gram, int64_t n_edges, int64_t e_own, int n_orb, int V, int n_l,
+                           int zdim, float* g_rb /* accumulated */, float* g_gate_part, void* stream);
+int lcao_geometry_bwd(const float* dist, const float* uvec, const float* g_rb, const float* g_u, int64_t n_edges, int n_orb,
+                      const float* orb_table, int rbf_kind, int cutoff_kind, float rc, float* g_vec, void* stream);
+
 size_t lcao_lds_bytes_coeff_mlp(int C, int V, int valence);
 
 /* Diagnostics only (tools/clock_probe.py): buffer of 2 x uint64 per wave of lcao_coeff_mlp_contract receiving

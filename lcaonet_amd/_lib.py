@@ -41,6 +41,13 @@ SIGNATURES = {
     "lcao_pair_contract": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],
     "lcao_edge_lcao_weight": [P, P, P, P, L, I, P, P],
     "lcao_edge_node_message": [P, P, P, P, P, P, P, L, I, P, P],
+    "lcao_act_bwd": [P, P, L, I, P, P],
+    "lcao_pair_pre": [P, P, P, P, L, I, P, P],
+    "lcao_message_bwd": [P, P, P, P, L, I, P, P, P],
+    "lcao_combine_bwd": [P, P, P, L, I, P, P, P],
+    "lcao_triplet_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, I, L, I, I, P, P, P, P, P, P],
+    "lcao_pair_contract_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, P, P, P],
+    "lcao_geometry_bwd": [P, P, P, P, L, I, P, I, I, F, P, P],
     "lcao_lds_bytes_coeff_mlp": [I, I, I],
     "lcao_debug_set_clock_probe": [P],
 }

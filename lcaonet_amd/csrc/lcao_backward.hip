@@ -1,0 +1,504 @@
+// lcao_backward.hip — activation-gradient (vector-Jacobian) kernels of the LCAOConv path: what
+// `-torch.autograd.grad(E, pos)` (lcaonet/model/lcaonet.py:310-317, regress_forces with direct_forces=False) needs at
+// inference.  Parameter gradients (training) are not built yet.
+//
+// Notation as in lcaonet_amd/model/lcaonet.py (p-space edges, species-pair table Tf, Gram form of the three-body
+// normalisation).  g_X denotes dE/dX.  Dense layers are differentiated with lcao_dense on transposed weights; the
+// kernels here are the element-wise / per-edge / per-triplet pieces.  No float atomics: every accumulation target is
+// owned by exactly one wave, or goes through a dense per-node scratch matrix that a second kernel sums in fixed order.
+#include "lcao_common.h"
+
+__device__ __forceinline__ float lcao_silu_grad(float x) {
+  // d/dx [x sigmoid(x)] = s (1 + x (1 - s))
+  const float s = lcao_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+// out = g * silu'(pre)                      (act == SILU)
+// out = g * s (1 - s), s = sigmoid(pre)     (act == SIGMOID)
+__global__ void k_act_bwd(const float* __restrict__ g, const float* __restrict__ pre, int64_t n, int act,
+                          float* __restrict__ out) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = pre[i];
+  float d = 1.0f;
+  if (act == LCAO_ACT_SILU) d = lcao_silu_grad(x);
+  else if (act == LCAO_ACT_SIGMOID) { const float s = lcao_sigmoid(x); d = s * (1.0f - s); }
+  out[i] = g[i] * d;
+}
+
+extern "C" int lcao_act_bwd(const float* g, const float* pre, int64_t n, int act, float* out, void* stream) {
+  if (n < 0 || act < 0 || act > 2) return LCAO_ERR_INVALID;
+  if (n == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g); LCAO_CHECK_PTR(pre); LCAO_CHECK_PTR(out);
+  hipLaunchKernelGGL(k_act_bwd, dim3(lcao_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, g, pre, n, act, out);
+  return lcao_launch_status();
+}
+
+// e4/e5 backward (lcaonet.py:207-213): msg = bw * silu(pre2), agg[s] = sum msg.
+//   g_msg[p] = g_agg[src_p[p]];  g_bw = g_msg * silu(pre2);  g_pre2 = g_msg * bw * silu'(pre2)
+__global__ void k_message_bwd(const float* __restrict__ g_agg, const int32_t* __restrict__ src_p,
+                              const float* __restrict__ bw, const float* __restrict__ pre2, int64_t E, int V,
+                              float* __restrict__ g_bw, float* __restrict__ g_pre2) {
+  int lane = threadIdx.x & 63;
+  int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; p < E; p += nwave) {
+    const float* ga = g_agg + (int64_t)src_p[p] * V;
+    for (int c = lane; c < V; c += 64) {
+      const float gm = ga[c], x = pre2[p * V + c];
+      g_bw[p * V + c] = gm * lcao_silu(x);
+      g_pre2[p * V + c] = gm * bw[p * V + c] * lcao_silu_grad(x);
+    }
+  }
+}
+
+extern "C" int lcao_message_bwd(const float* g_agg, const int32_t* src_p, const float* bw, const float* pre2,
+                                int64_t n_edges, int V, float* g_bw, float* g_pre2, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_agg); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(pre2); LCAO_CHECK_PTR(g_bw);
+  LCAO_CHECK_PTR(g_pre2);
+  hipLaunchKernelGGL(k_message_bwd, dim3(lcao_blocks(n_edges, 4, 65536)), dim3(256), 0, (hipStream_t)stream, g_agg,
+                     src_p, bw, pre2, n_edges, V, g_bw, g_pre2);
+  return lcao_launch_status();
+}
+
+// pre1[p] = Ps[src] + Pt[dst]   (the pre-activation of the first f_node layer, needed for silu')
+__global__ void k_pair_pre(const float* __restrict__ Ps, const float* __restrict__ Pt,
+                           const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, int64_t E, int V,
+                           float* __restrict__ pre1) {
+  int lane = threadIdx.x & 63;
+  int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; p < E; p += nwave) {
+    const float* a = Ps + (int64_t)src_p[p] * V;
+    const float* b = Pt + (int64_t)dst_p[p] * V;
+    for (int c = lane; c < V; c += 64) pre1[p * V + c] = a[c] + b[c];
+  }
+}
+
+extern "C" int lcao_pair_pre(const float* Ps, const float* Pt, const int32_t* src_p, const int32_t* dst_p,
+                             int64_t n_edges, int V, float* pre1, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(pre1);
+  hipLaunchKernelGGL(k_pair_pre, dim3(lcao_blocks(n_edges, 4, 65536)), dim3(256), 0, (hipStream_t)stream, Ps, Pt, src_p,
+                     dst_p, n_edges, V, pre1);
+  return lcao_launch_status();
+}
+
+// e3 backward (lcaonet.py:192-204): u = B (1 + ft), lw = u / max(|u|, eps).
+//   g_u = (g_lw - lw (lw . g_lw)) / |u|   (0 where |u| <= eps: the clamped branch is constant in direction 0/eps)
+//   g_B = g_u (1 + ft);  g_ft = g_u B
+template <int R>
+__global__ void k_combine_bwd(const float* __restrict__ g_lw, const float* __restrict__ B,
+                              const float* __restrict__ ft, int64_t E, int V, float* __restrict__ g_B,
+                              float* __restrict__ g_ft) {
+  int lane = threadIdx.x & 63;
+  int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; p < E; p += nwave) {
+    float u[R], gl[R], b[R], f[R];
+    float n2 = 0.f, dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int ch = lane + 64 * r;
+      b[r] = f[r] = u[r] = gl[r] = 0.f;
+      if (ch < V) {
+        b[r] = B[p * V + ch];
+        f[r] = ft[p * V + ch];
+        u[r] = b[r] + b[r] * f[r];
+        gl[r] = g_lw[p * V + ch];
+      }
+      n2 += u[r] * u[r];
+      dot += u[r] * gl[r];
+    }
+    n2 = lcao_wave_sum(n2);
+    dot = lcao_wave_sum(dot);
+    const float nrm = sqrtf(n2);
+    const bool live = nrm > 1e-12f;
+    const float inv = live ? 1.0f / nrm : 1e12f;
+    // lw = u * inv;  g_u = inv * (g_lw - lw (lw . g_lw)) when live, inv * g_lw in the clamped (constant-scale) branch
+    const float proj = live ? dot * inv * inv : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int ch = lane + 64 * r;
+      if (ch < V) {
+        const float gu = inv * (gl[r] - u[r] * proj);
+        g_B[p * V + ch] = gu * (1.0f + f[r]);
+        g_ft[p * V + ch] = gu * b[r];
+      }
+    }
+  }
+}
+
+extern "C" int lcao_combine_bwd(const float* g_lw, const float* B, const float* ft, int64_t n_edges, int V, float* g_B,
+                                float* g_ft, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_lw); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(ft); LCAO_CHECK_PTR(g_B); LCAO_CHECK_PTR(g_ft);
+  dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  int R = (V + 63) / 64;
+  if (R == 1) hipLaunchKernelGGL(k_combine_bwd<1>, grid, block, 0, st, g_lw, B, ft, n_edges, V, g_B, g_ft);
+  else if (R == 2) hipLaunchKernelGGL(k_combine_bwd<2>, grid, block, 0, st, g_lw, B, ft, n_edges, V, g_B, g_ft);
+  else if (R <= 4) hipLaunchKernelGGL(k_combine_bwd<4>, grid, block, 0, st, g_lw, B, ft, n_edges, V, g_B, g_ft);
+  else hipLaunchKernelGGL(k_combine_bwd<8>, grid, block, 0, st, g_lw, B, ft, n_edges, V, g_B, g_ft);
+  return lcao_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// e2 backward — three-body term  tbw[p] = sum_{q in In(s), q != p} sum_l w_pql Ag[q,l,:],
+//   w_pql = Y_l(c) * inv,  c = u_p . u_q,  inv = 1 / max(sqrt(m), eps),  m = Y^T G_q Y   (G upper-triangular, 10 floats)
+// One wave per in-edge q (it owns g_Ag[q], g_gram[q], and its part of g_u[q]); the per-triplet scalar
+// g_c = dE/dc goes to the dense per-node scratch gc[tbase[s] + j * m_out + i] (j = index of q in In(s), i = index of p
+// in Out(s)) so that a second kernel can form g_u[p] = sum_q g_c u_q without atomics.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lcao_y_l0_grad(float c, int l) {
+  switch (l) {
+    case 0: return 0.0f;
+    case 1: return 0.48860251190292f;
+    case 2: return 2.0f * 0.94617469575756f * c;
+    default: return 0.373176332590115f * (15.0f * c * c - 3.0f);
+  }
+}
+
+template <int R>
+__global__ void k_triplet_bwd_q(const float* __restrict__ g_tbw, const float* __restrict__ Ag,
+                                const float* __restrict__ gram, const float* __restrict__ uvec_p,
+                                const int32_t* __restrict__ dst_p, const int32_t* __restrict__ in_ptr,
+                                const int32_t* __restrict__ in_pos, const int32_t* __restrict__ out_ptr,
+                                const int64_t* __restrict__ tbase, int64_t E, int n_own, int V, int NL,
+                                float* __restrict__ g_Ag, float* __restrict__ g_gram, float* __restrict__ g_uq,
+                                float* __restrict__ gc) {
+  int lane = threadIdx.x & 63;
+  int64_t jj = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;   // position in the in-edge lists
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t n_in_total = in_ptr[n_own];
+  for (; jj < n_in_total; jj += nwave) {
+    const int q = in_pos[jj];
+    const int s = dst_p[q];                    // centre node whose in-list holds q
+    const int j = (int)(jj - in_ptr[s]);
+    const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
+    float a[4][R], ga[4][R];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int ch = lane + 64 * r;
+        a[l][r] = (l < NL && ch < V) ? Ag[((int64_t)q * NL + l) * V + ch] : 0.f;
+        ga[l][r] = 0.f;
+      }
+    float G[10], gG[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { G[i] = gram[(int64_t)q * 10 + i]; gG[i] = 0.f; }
+    const float qx = uvec_p[3 * (int64_t)q], qy = uvec_p[3 * (int64_t)q + 1], qz = uvec_p[3 * (int64_t)q + 2];
+    float gux = 0.f, guy = 0.f, guz = 0.f;
+    for (int i = 0; i < m_out; ++i) {
+      const int p = p0 + i;
+      float gcv = 0.f;
+      if (p != q) {
+        const float px = uvec_p[3 * (int64_t)p], py = uvec_p[3 * (int64_t)p + 1], pz = uvec_p[3 * (int64_t)p + 2];
+        const float c = px * qx + py * qy + pz * qz;
+        float y[4], dy[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { y[l] = (l < NL) ? lcao_y_l0(c, l) : 0.f; dy[l] = (l < NL) ? lcao_y_l0_grad(c, l) : 0.f; }
+        // m = Y^T G Y and (G Y)_l with upper-triangular storage idx(l,l2) = l*4 - l(l-1)/2 + (l2-l)
+        float GY[4] = {0.f, 0.f, 0.f, 0.f};
+        float m = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+          for (int l2 = l; l2 < 4; ++l2) {
+            const float gv = G[l * 4 - (l * (l - 1)) / 2 + (l2 - l)];
+            if (l == l2) { m += y[l] * y[l] * gv; GY[l] += gv * y[l]; }
+            else { m += 2.0f * y[l] * y[l2] * gv; GY[l] += gv * y[l2]; GY[l2] += gv * y[l]; }
+          }
+        const float nrm = sqrtf(fmaxf(m, 0.f));
+        const bool live = nrm > 1e-12f;
+        const float inv = live ? 1.0f / nrm : 1e12f;
+        // g_w_l = g_tbw[p] . Ag[q,l]
+        float gt[R];
+        float gw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          int ch = lane + 64 * r;
+          gt[r] = ch < V ? g_tbw[(int64_t)p * V + ch] : 0.f;
+#pragma unroll
+          for (int l = 0; l < 4; ++l) gw[l] += gt[r] * a[l][r];
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) gw[l] = (l < NL) ? lcao_wave_sum(gw[l]) : 0.f;
+        float g_inv = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) g_inv += gw[l] * y[l];
+        const float g_m = live ? -0.5f * g_inv * inv * inv * inv : 0.f;
+        float gY[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) gY[l] = gw[l] * inv + 2.0f * g_m * GY[l];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) gcv += gY[l] * dy[l];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+          for (int l2 = l; l2 < 4; ++l2)
+            gG[l * 4 - (l * (l - 1)) / 2 + (l2 - l)] += g_m * (l == l2 ? y[l] * y[l] : 2.0f * y[l] * y[l2]);
+        // g_Ag[q,l] += w_l g_tbw[p]
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const float w = y[l] * inv;
+#pragma unroll
+          for (int r = 0; r < R; ++r) ga[l][r] += w * gt[r];
+        }
+        gux += gcv * px; guy += gcv * py; guz += gcv * pz;
+      }
+      if (lane == 0) gc[tbase[s] + (int64_t)j * m_out + i] = gcv;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (l < NL) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          int ch = lane + 64 * r;
+          if (ch < V) g_Ag[((int64_t)q * NL + l) * V + ch] = ga[l][r];
+        }
+      }
+    if (lane < 10) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) v = (lane == i) ? gG[i] : v;
+      g_gram[(int64_t)q * 10 + lane] = v;
+    }
+    if (lane == 0) { g_uq[3 * (int64_t)q] = gux; g_uq[3 * (int64_t)q + 1] = guy; g_uq[3 * (int64_t)q + 2] = guz; }
+  }
+}
+
+// g_u[p] (as the OUT-edge of its centre) = sum_{q in In(s)} g_c[p,q] u_q ;  one thread per out-edge
+__global__ void k_triplet_bwd_p(const float* __restrict__ gc, const float* __restrict__ uvec_p,
+                                const int32_t* __restrict__ src_p, const int32_t* __restrict__ in_ptr,
+                                const int32_t* __restrict__ in_pos, const int32_t* __restrict__ out_ptr,
+                                const int64_t* __restrict__ tbase, int64_t e_own, float* __restrict__ g_up) {
+  int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= e_own) return;
+  const int s = src_p[p];
+  const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0, i = (int)(p - p0);
+  const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  for (int j = 0; j < m_in; ++j) {
+    const int q = in_pos[j0 + j];
+    const float g = gc[tbase[s] + (int64_t)j * m_out + i];
+    gx += g * uvec_p[3 * (int64_t)q]; gy += g * uvec_p[3 * (int64_t)q + 1]; gz += g * uvec_p[3 * (int64_t)q + 2];
+  }
+  g_up[3 * p] = gx; g_up[3 * p + 1] = gy; g_up[3 * p + 2] = gz;
+}
+
+extern "C" int lcao_triplet_bwd(const float* g_tbw, const float* Ag, const float* gram, const float* uvec_p,
+                                const int32_t* src_p, const int32_t* dst_p, const int32_t* in_ptr, const int32_t* in_pos,
+                                const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t e_own, int n_own,
+                                int64_t n_in_total, int V, int n_l, float* g_Ag, float* g_gram, float* g_uq, float* g_up,
+                                float* gc_scratch, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || n_own < 0) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  if (n_edges == 0 || n_own == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_tbw); LCAO_CHECK_PTR(Ag); LCAO_CHECK_PTR(gram); LCAO_CHECK_PTR(uvec_p); LCAO_CHECK_PTR(src_p);
+  LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(in_ptr); LCAO_CHECK_PTR(in_pos); LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase);
+  LCAO_CHECK_PTR(g_Ag); LCAO_CHECK_PTR(g_gram); LCAO_CHECK_PTR(g_uq); LCAO_CHECK_PTR(g_up); LCAO_CHECK_PTR(gc_scratch);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n_in_total > 0 ? n_in_total : 1, 4, 65536)), block(256);
+  int R = (V + 63) / 64;
+#define TB_LAUNCH(RR)                                                                                               \
+  hipLaunchKernelGGL(k_triplet_bwd_q<RR>, grid, block, 0, st, g_tbw, Ag, gram, uvec_p, dst_p, in_ptr, in_pos, out_ptr, \
+                     tbase, n_edges, n_own, V, n_l, g_Ag, g_gram, g_uq, gc_scratch)
+  if (R == 1) TB_LAUNCH(1);
+  else if (R == 2) TB_LAUNCH(2);
+  else if (R <= 4) TB_LAUNCH(4);
+  else TB_LAUNCH(8);
+#undef TB_LAUNCH
+  hipLaunchKernelGGL(k_triplet_bwd_p, dim3(lcao_blocks(e_own > 0 ? e_own : 1, 256)), dim3(256), 0, st, gc_scratch, uvec_p,
+                     src_p, in_ptr, in_pos, out_ptr, tbase, e_own, g_up);
+  return lcao_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// e1 backward, species-pair form:  A[l] = sum_{d in l} rb[e,d] Tf[pair,d,:],  Ag = A gate[src],  B = sum_l A,
+// gram = A A^T (upper triangle).   Given g_Ag, g_B, g_gram:
+//   g_A[l]  = g_Ag[l] gate + g_B + sum_l2 gGsym[l,l2] A[l2]      (gGsym[l,l] = 2 g_gram[l,l], off-diagonal = g_gram)
+//   g_rb[e,d] = g_A[l(d)] . Tf[pair,d,:]
+//   g_gate_part[p,:] = sum_l g_Ag[l] A[l]      (segment-summed over out-edges of src by the caller)
+// One wave per edge.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ void k_pair_contract_bwd(const float* __restrict__ Tf, const float* __restrict__ rb,
+                                    const int32_t* __restrict__ order, const int32_t* __restrict__ l_of_d,
+                                    const int64_t* __restrict__ z, const int32_t* __restrict__ src_p,
+                                    const int32_t* __restrict__ dst_p, const float* __restrict__ gate,
+                                    const float* __restrict__ g_Ag, const float* __restrict__ g_B,
+                                    const float* __restrict__ g_gram, int64_t E, int64_t e_own, int D, int V, int NL,
+                                    int zdim, float* __restrict__ g_rb, float* __restrict__ g_gate_part) {
+  int lane = threadIdx.x & 63;
+  int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; p < E; p += nwave) {
+    const int64_t e = order ? order[p] : p;
+    const int s = src_p[p];
+    const int64_t pair = z[s] * zdim + z[dst_p[p]];
+    const float* t = Tf + pair * (int64_t)D * V;
+    float a[4][R], gA[4][R];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[l][r] = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float w = rb[e * D + d];
+      const int l = l_of_d[d];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int ch = lane + 64 * r;
+        const float v = ch < V ? w * t[d * V + ch] : 0.f;
+        a[0][r] += (l == 0) ? v : 0.f; a[1][r] += (l == 1) ? v : 0.f;
+        a[2][r] += (l == 2) ? v : 0.f; a[3][r] += (l == 3) ? v : 0.f;
+      }
+    }
+    float gG[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) gG[i] = g_gram[p * 10 + i];
+    const bool own = p < e_own;   // only owned out-edges carry a two-body term (g_B); ghost out-edges feed the 3-body term only
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int ch = lane + 64 * r;
+      const float gt = ch < V ? gate[(int64_t)s * V + ch] : 0.f;
+      const float gb = (own && ch < V) ? g_B[p * V + ch] : 0.f;
+      float gpart = 0.f;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        float gag = (l < NL && ch < V) ? g_Ag[(p * NL + l) * V + ch] : 0.f;
+        gpart += gag * a[l][r];
+        float v = gag * gt + ((l < NL) ? gb : 0.f);
+#pragma unroll
+        for (int l2 = 0; l2 < 4; ++l2) {
+          const int lo = l < l2 ? l : l2, hi = l < l2 ? l2 : l;
+          const float gs = gG[lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo)] * (l == l2 ? 2.0f : 1.0f);
+          v += gs * a[l2][r];
+        }
+        gA[l][r] = v;
+      }
+      if (ch < V) g_gate_part[p * V + ch] = gpart;
+    }
+    for (int d = 0; d < D; ++d) {
+      const int l = l_of_d[d];
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int ch = lane + 64 * r;
+        const float tv = ch < V ? t[d * V + ch] : 0.f;
+        const float g = l == 0 ? gA[0][r] : (l == 1 ? gA[1][r] : (l == 2 ? gA[2][r] : gA[3][r]));
+        acc += g * tv;
+      }
+      acc = lcao_wave_sum(acc);
+      if (lane == 0) g_rb[e * D + d] += acc;   // accumulated over layers (the caller zeroes it once per forward)
+    }
+  }
+}
+
+extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                                      const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
+                                      const float* g_Ag, const float* g_B, const float* g_gram, int64_t n_edges,
+                                      int64_t e_own, int n_orb, int V, int n_l, int zdim, float* g_rb,
+                                      float* g_gate_part, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (n_orb <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(Tf); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p);
+  LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(g_Ag); LCAO_CHECK_PTR(g_B); LCAO_CHECK_PTR(g_gram);
+  LCAO_CHECK_PTR(g_rb); LCAO_CHECK_PTR(g_gate_part);
+  dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  int R = (V + 63) / 64;
+#define PB_LAUNCH(RR)                                                                                                 \
+  hipLaunchKernelGGL(k_pair_contract_bwd<RR>, grid, block, 0, st, Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, \
+                     g_gram, n_edges, e_own, n_orb, V, n_l, zdim, g_rb, g_gate_part)
+  if (R == 1) PB_LAUNCH(1);
+  else if (R == 2) PB_LAUNCH(2);
+  else if (R <= 4) PB_LAUNCH(4);
+  else PB_LAUNCH(8);
+#undef PB_LAUNCH
+  return lcao_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// basis + geometry backward: g_rb (E,D), g_u (E,3) -> g_vec (E,3) = dE/d(vec_e), vec = pos[t] - pos[s] + shift @ lattice.
+//   rb[e,d] = R_d(r):  g_r = sum_d g_rb[e,d] R_d'(r);   u = vec / r:  g_vec = (g_u - u (u . g_u)) / r + g_r u
+// R_nl' for the hydrogen basis: R = cw(r) f(zeta), f = C P(zeta) zeta^l exp(-zeta/2), zeta = s r
+//   R' = cw'(r) f + cw s C [P' zeta^l + l P zeta^(l-1) - P zeta^l / 2] exp(-zeta/2)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lcao_cutoff_grad(float r, float rc, int kind) {
+  if (kind == LCAO_CUTOFF_NONE || !(r <= rc)) return 0.0f;
+  const float x = r / rc;
+  if (kind == LCAO_CUTOFF_ENVELOPE) {
+    const float x4 = x * x * x * x;
+    return (-105.0f * x4 + 210.0f * x4 * x - 105.0f * x4 * x * x) / rc;   // d/dx (1 - 21x^5 + 35x^6 - 15x^7)
+  } else if (kind == LCAO_CUTOFF_POLYNOMIAL) {
+    const float x2 = x * x;
+    return (-30.0f * x2 * x2 + 60.0f * x2 * x - 30.0f * x2) / rc;         // d/dx (1 - 6x^5 + 15x^4 - 10x^3)
+  }
+  return -0.5f * sinf(r * 3.14159265358979323846f / rc) * 3.14159265358979323846f / rc;
+}
+
+__global__ void k_geometry_bwd(const float* __restrict__ dist, const float* __restrict__ uvec,
+                               const float* __restrict__ g_rb, const float* __restrict__ g_u, int64_t E, int D,
+                               const float* __restrict__ tab, int rbf_kind, int cutoff_kind, float rc,
+                               float* __restrict__ g_vec) {
+  int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float r = dist[e];
+  const float cw = lcao_cutoff_eval(r, rc, cutoff_kind), dcw = lcao_cutoff_grad(r, rc, cutoff_kind);
+  float g_r = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float* row = tab + d * LCAO_ORB_STRIDE;
+    float dR;
+    if (rbf_kind == LCAO_RBF_HYDROGEN) {
+      const float s = row[0], C = row[1];
+      const int l = (int)row[2], k = (int)row[3];
+      const float zeta = s * r;
+      float P = 0.f, dP = 0.f;   // Horner for P and P'
+      for (int i = k; i >= 0; --i) { dP = dP * zeta + P; P = P * zeta + row[4 + i]; }
+      const float zl = (l == 0) ? 1.0f : (l == 1 ? zeta : (l == 2 ? zeta * zeta : zeta * zeta * zeta));
+      const float zlm1 = (l <= 1) ? 1.0f : (l == 2 ? zeta : zeta * zeta);   // zeta^(l-1) (unused when l == 0)
+      const float ex = expf(-0.5f * zeta);
+      const float f = C * P * zl * ex;
+      const float df = C * s * ex * (dP * zl + (l > 0 ? (float)l * P * zlm1 : 0.f) - 0.5f * P * zl);
+      dR = dcw * f + cw * df;
+    } else {
+      const float kk = row[11] / rc;
+      const float sn = sinf(kk * r), cs = cosf(kk * r);
+      dR = dcw * sn / r + cw * (kk * cs / r - sn / (r * r));
+    }
+    g_r += g_rb[e * D + d] * dR;
+  }
+  const float ux = uvec[3 * e], uy = uvec[3 * e + 1], uz = uvec[3 * e + 2];
+  const float gx = g_u[3 * e], gy = g_u[3 * e + 1], gz = g_u[3 * e + 2];
+  const float dot = ux * gx + uy * gy + uz * gz;
+  g_vec[3 * e] = (gx - ux * dot) / r + g_r * ux;
+  g_vec[3 * e + 1] = (gy - uy * dot) / r + g_r * uy;
+  g_vec[3 * e + 2] = (gz - uz * dot) / r + g_r * uz;
+}
+
+extern "C" int lcao_geometry_bwd(const float* dist, const float* uvec, const float* g_rb, const float* g_u,
+                                 int64_t n_edges, int n_orb, const float* orb_table, int rbf_kind, int cutoff_kind,
+                                 float rc, float* g_vec, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (n_orb <= 0 || rbf_kind < 0 || rbf_kind > 1 || cutoff_kind < 0 || cutoff_kind > 3) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(dist); LCAO_CHECK_PTR(uvec); LCAO_CHECK_PTR(g_rb); LCAO_CHECK_PTR(g_u); LCAO_CHECK_PTR(orb_table);
+  LCAO_CHECK_PTR(g_vec);
+  hipLaunchKernelGGL(k_geometry_bwd, dim3(lcao_blocks(n_edges, 256)), dim3(256), 0, (hipStream_t)stream, dist, uvec, g_rb,
+                     g_u, n_edges, n_orb, orb_table, rbf_kind, cutoff_kind, rc, g_vec);
+  return lcao_launch_status();
+}

@@ -649,6 +649,69 @@ __global__ __launch_bounds__(256) void k_pair_contract(const float* __restrict__
   }
 }
 
+// any-V fallback of k_pair_contract: one wave per edge, lanes over V (R values per lane)
+template <int R>
+__global__ void k_pair_contract_any(const float* __restrict__ Tf, const float* __restrict__ rb,
+                                    const int32_t* __restrict__ order, const int32_t* __restrict__ l_of_d,
+                                    const int64_t* __restrict__ z, const int32_t* __restrict__ src_p,
+                                    const int32_t* __restrict__ dst_p, const float* __restrict__ gate, int64_t E, int D,
+                                    int V, int NL, int zdim, float* __restrict__ Ag, float* __restrict__ B,
+                                    float* __restrict__ gram) {
+  int lane = threadIdx.x & 63;
+  int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; p < E; p += nwave) {
+    const int64_t e = order ? order[p] : p;
+    const int s = src_p[p];
+    const int64_t pair = z[s] * zdim + z[dst_p[p]];
+    const float* t = Tf + pair * (int64_t)D * V;
+    float a[4][R];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[l][r] = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float w = rb[e * D + d];
+      const int l = l_of_d[d];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ch = lane + 64 * r;
+        const float v = ch < V ? w * t[d * V + ch] : 0.f;
+        a[0][r] += (l == 0) ? v : 0.f; a[1][r] += (l == 1) ? v : 0.f;
+        a[2][r] += (l == 2) ? v : 0.f; a[3][r] += (l == 3) ? v : 0.f;
+      }
+    }
+    int gi = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+      for (int l2 = l; l2 < 4; ++l2) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc += a[l][r] * a[l2][r];
+        acc = lcao_wave_sum(acc);
+        if (lane == 0) gram[p * 10 + gi] = acc;
+        ++gi;
+      }
+    const float* gt = gate + (int64_t)s * V;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ch = lane + 64 * r;
+      if (ch < V) {
+        const float gg = gt[ch];
+        float bsum = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+          if (l < NL) {
+            Ag[(p * NL + l) * V + ch] = a[l][r] * gg;
+            bsum += a[l][r];
+          }
+        B[p * V + ch] = bsum;
+      }
+    }
+  }
+}
+
 extern "C" int lcao_pair_contract(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
                                   const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
                                   int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* Ag, float* B, float* gram,
@@ -670,5 +733,18 @@ extern "C" int lcao_pair_contract(const float* Tf, const float* rb, const int32_
   PC_V(128) PC_V(64) PC_V(32)
 #undef PC_V
 #undef PC_CASE
-  return LCAO_ERR_UNSUPPORTED;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  {
+    dim3 g2(lcao_blocks(n_edges, 4, 65536));
+    int R = (V + 63) / 64;
+#define PCA(RR)                                                                                                  \
+  hipLaunchKernelGGL(k_pair_contract_any<RR>, g2, block, 0, st, Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_edges, \
+                     n_orb, V, n_l, zdim, Ag, B, gram)
+    if (R == 1) PCA(1);
+    else if (R == 2) PCA(2);
+    else if (R <= 4) PCA(4);
+    else PCA(8);
+#undef PCA
+  }
+  return lcao_launch_status();
 }

@@ -864,6 +864,54 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
   }
 }
 
+// any-V fallback of k_triplet_gemm (same Gram-form arithmetic on the VALU): one wave per out-edge, lanes over V
+template <int R>
+__global__ void k_triplet_gram_any(const float* __restrict__ Ag, const float* __restrict__ gram,
+                                   const float* __restrict__ uvec_p, const int32_t* __restrict__ in_ptr,
+                                   const int32_t* __restrict__ in_pos, const int32_t* __restrict__ out_ptr, int n_nodes,
+                                   int V, int NL, float* __restrict__ tbw) {
+  int lane = threadIdx.x & 63;
+  int64_t wv = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t s = wv; s < n_nodes; s += nwave) {
+    const int p0 = out_ptr[s], p1 = out_ptr[s + 1];
+    const int j0 = in_ptr[s], j1 = in_ptr[s + 1];
+    for (int p = p0; p < p1; ++p) {
+      const float ux = uvec_p[3 * (int64_t)p], uy = uvec_p[3 * (int64_t)p + 1], uz = uvec_p[3 * (int64_t)p + 2];
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const int q = in_pos[j];
+        if (q == p) continue;
+        const float c = ux * uvec_p[3 * (int64_t)q] + uy * uvec_p[3 * (int64_t)q + 1] + uz * uvec_p[3 * (int64_t)q + 2];
+        float y[4], m = 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) y[l] = lcao_y_l0(c, l);
+        for (int l = 0; l < NL; ++l)
+          for (int l2 = l; l2 < NL; ++l2) {
+            const float gv = gram[(int64_t)q * 10 + gram_idx(l, l2)];
+            m += (l == l2 ? 1.0f : 2.0f) * y[l] * y[l2] * gv;
+          }
+        const float inv = 1.0f / fmaxf(sqrtf(fmaxf(m, 0.f)), 1e-12f);
+        for (int l = 0; l < NL; ++l) {
+          const float w = y[l] * inv;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int ch = lane + 64 * r;
+            if (ch < V) acc[r] += w * Ag[((int64_t)q * NL + l) * V + ch];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ch = lane + 64 * r;
+        if (ch < V) tbw[(int64_t)p * V + ch] = acc[r];
+      }
+    }
+  }
+}
+
 extern "C" int lcao_triplet_gemm(const float* Ag, const float* gram, const float* uvec_p, const int32_t* in_ptr,
                                  const int32_t* in_pos, const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int V,
                                  int n_l, float* tbw, void* stream) {
@@ -887,5 +935,18 @@ extern "C" int lcao_triplet_gemm(const float* Ag, const float* gram, const float
   TG_V(128) TG_V(64) TG_V(32)
 #undef TG_V
 #undef TG_CASE
-  return LCAO_ERR_UNSUPPORTED;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  {
+    int R = (V + 63) / 64;
+    dim3 g2((unsigned)groups), b2(256);
+#define TGA(RR)                                                                                                    \
+  hipLaunchKernelGGL(k_triplet_gram_any<RR>, g2, b2, 0, st, Ag, gram, uvec_p, in_ptr, in_pos, out_ptr, (int)n_nodes, V, \
+                     n_l, tbw)
+    if (R == 1) TGA(1);
+    else if (R == 2) TGA(2);
+    else if (R <= 4) TGA(4);
+    else TGA(8);
+#undef TGA
+  }
+  return lcao_launch_status();
 }

@@ -1,0 +1,184 @@
+"""Autograd forces at inference: F = -dE/dpos for `regress_forces=True, direct_forces=False`
+(reference lcaonet/model/lcaonet.py:497-498, 310-317).
+
+The reference records an autograd graph through every op (create_graph=True).  Here the forward pass of the
+species-pair-table form (model/lcaonet.py, cst_mode="pair") keeps the few per-layer tensors the chain rule needs and a
+hand-written reverse sweep runs on the HIP kernels of csrc/lcao_backward.hip: dense layers are differentiated by
+`lcao_dense` on transposed weights, everything else by small vector-Jacobian kernels.  Only activation gradients are
+propagated (inference); parameter gradients — training — are the remaining part of SURVEY.md §8f-3.
+
+Restrictions (each raises NotImplementedError): eval mode, SiLU activations, add_valence=False, built-in cutoff / basis.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+from ..data.keys import GraphKeys
+from ..nn.scatter import scatter
+
+ACT = ops.ACT_SILU
+
+
+def _t(w: Tensor) -> Tensor:
+    return w.detach().t().contiguous()
+
+
+def _in_sum(rows: Tensor, ctx, n_nodes: int) -> Tensor:
+    """sum of per-edge rows over the IN-edges of every node (deterministic: in_pos order)."""
+    return ops.segment_sum(ops.gather_rows(rows, ctx.in_pos), ctx.in_ptr[: n_nodes + 1])
+
+
+@torch.no_grad()
+def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim):
+    """One interaction layer in pair-table form; returns (x_new, saved tensors for the reverse sweep)."""
+    V = layer.emb_size_conv
+    wn, bn_ = layer.node_weight.weight.detach(), layer.node_weight.bias.detach()
+    xs = ops.dense(x, wn[:V], bn_[:V])
+    xk = ops.dense(x, wn[V:], bn_[V:])
+    gate = torch.sigmoid(xk)
+    w1 = layer.f_node[0].weight.detach()
+    Ps = ops.dense(xs, w1[:, :V].contiguous(), layer.f_node[0].bias.detach())
+    Pt = ops.dense(xs, w1[:, V:].contiguous())
+    Tf = ops.dense(ops.dense(Tf_in, layer.f_coeffs[0].weight.detach(), None, ACT), layer.f_coeffs[2].weight.detach(),
+                   None, ACT)
+    Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
+    tbw = ops.triplet_gemm(Ag, gram, uvec_p, ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
+    ft = ops.dense(tbw, layer.f_three[0].weight.detach())
+    lw = ops.edge_combine(ft, B, None)
+    bw = ops.dense(lw, layer.basis_weight.weight.detach())
+    pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
+    h1 = torch.nn.functional.silu(pre1)
+    pre2 = ops.dense(h1, layer.f_node[2].weight.detach(), layer.f_node[2].bias.detach())
+    agg = ops.segment_sum(bw, ctx.out_ptr, torch.nn.functional.silu(pre2))
+    x_new = ops.dense(agg, layer.out_weight.weight.detach(), None, ops.ACT_NONE, x)
+    saved = dict(xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, ft=ft, bw=bw, pre1=pre1, pre2=pre2)
+    return x_new, saved
+
+
+@torch.no_grad()
+def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tbase, n_trip_dense, g_rb, g_u_p):
+    """Reverse sweep of one layer: g_xnew = dE/dx_out -> dE/dx_in; accumulates dE/drb (orig order) and dE/du (p-space)."""
+    V = layer.emb_size_conv
+    N, E = g_xnew.shape[0], ctx.n_edges
+    # x' = x + agg Wout^T
+    g_agg = ops.dense(g_xnew, _t(layer.out_weight.weight))
+    # msg = bw * silu(pre2), agg = segment sum
+    g_bw, g_pre2 = ops.message_bwd(g_agg, ctx.src_p, sv["bw"], sv["pre2"])
+    g_h1 = ops.dense(g_pre2, _t(layer.f_node[2].weight))
+    g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
+    g_Ps = ops.segment_sum(g_pre1, ctx.out_ptr)          # pre1 = Ps[src] + Pt[dst]
+    g_Pt = _in_sum(g_pre1, ctx, N)
+    # bw = lw Wb^T ; lw = normalize(B (1 + ft)) ; ft = tbw W3^T
+    g_lw = ops.dense(g_bw, _t(layer.basis_weight.weight))
+    g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
+    g_tbw = ops.dense(g_ft, _t(layer.f_three[0].weight))
+    # three-body term
+    g_Ag, g_gram, g_uq, g_up = ops.triplet_bwd(g_tbw, sv["Ag"], sv["gram"], uvec_p, ctx.src_p, ctx.dst_p, ctx.in_ptr,
+                                               ctx.in_pos, ctx.out_ptr, tbase, n_trip_dense, E, N)
+    g_u_p += g_uq
+    g_u_p += g_up
+    # pair-table contraction: A from rb and Tf; Ag = A gate; B; gram
+    g_gate_part = ops.pair_contract_bwd(sv["Tf"], rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"], g_Ag, g_B,
+                                        g_gram, E, n_l, zdim, g_rb)
+    g_gate = ops.segment_sum(g_gate_part, ctx.out_ptr)
+    g_xk = ops.act_bwd(g_gate, sv["xk"], ops.ACT_SIGMOID)
+    # node level: Ps = xs Wa^T + b, Pt = xs Wb^T ; [xs | xk] = x Wnw^T + b
+    w1 = layer.f_node[0].weight.detach()
+    g_xs = ops.dense(g_Ps, w1[:, :V].t().contiguous())
+    g_xs = ops.dense(g_Pt, w1[:, V:].t().contiguous(), None, ops.ACT_NONE, g_xs)
+    wn = layer.node_weight.weight.detach()
+    g_x = ops.dense(g_xs, wn[:V].t().contiguous(), None, ops.ACT_NONE, g_xnew)      # + residual path
+    g_x = ops.dense(g_xk, wn[V:].t().contiguous(), None, ops.ACT_NONE, g_x)
+    return g_x
+
+
+def _check_supported(model):
+    if model.training:
+        raise NotImplementedError("autograd forces: eval mode only (BatchNorm batch statistics are not differentiated)")
+    if model.add_valence:
+        raise NotImplementedError("autograd forces with add_valence=True are not built yet")
+    acts = [model.int_layers[0].f_coeffs[1], model.int_layers[0].f_node[1], model.out_layer.out_lin[1]]
+    if not all(type(a) is nn.SiLU for a in acts):
+        raise NotImplementedError("autograd forces are built for the default SiLU activation")
+    if getattr(model.rbf, "rbf_kind", None) is None or getattr(model.rbf.cutoff_net, "kind", None) is None:
+        raise NotImplementedError("autograd forces need a built-in radial basis and cutoff")
+
+
+@torch.no_grad()
+def forward_with_autograd_forces(model, graph):
+    """Returns (out (B, out_size), force) with force = -d(sum_b out[b, i])/dpos: (N, 3) for out_size == 1,
+    (N, out_size, 3) otherwise — the shapes of lcaonet.py:310-317."""
+    from .lcaonet import EdgeContext
+    from .base import BaseMPNN
+
+    _check_supported(model)
+    batch_idx = graph.get(GraphKeys.Batch_idx)
+    z, pos = graph[GraphKeys.Z], graph[GraphKeys.Pos]
+    idx_s, idx_t = graph[GraphKeys.Edge_idx]
+    ops._dev(pos, "graph.pos")
+    N = z.size(0)
+    ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], N)
+    graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
+    dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
+    uvec_p = ctx.uvec_p(uvec)
+    rb = model.rbf(dist)
+    x, cst_pair, zdim = model.emb_layer.forward_pair_table(z)
+    l_of_d, n_l = model.shbf.l_of_d, model.n_l
+
+    saved, x_in = [], x
+    for layer in model.int_layers:
+        x_in, sv = layer_forward_saving(layer, x_in, cst_pair, rb, uvec_p, ctx, l_of_d, n_l, z, zdim)
+        saved.append(sv)
+    xL = x_in
+
+    # output head (lcaonet.py:290-298) with the pre-activations kept
+    lin = model.out_layer.out_lin
+    pre_a = ops.dense(xL, lin[0].weight.detach(), lin[0].bias.detach())
+    a = torch.nn.functional.silu(pre_a)
+    pre_b = ops.dense(a, lin[2].weight.detach(), lin[2].bias.detach())
+    b = torch.nn.functional.silu(pre_b)
+    prop = ops.dense(b, lin[4].weight.detach())
+    lat = graph.get(GraphKeys.Lattice)
+    n_graphs = lat.shape[0] if (batch_idx is not None and lat is not None and lat.dim() == 3) else None
+    red = "sum" if model.out_layer.is_extensive else "mean"
+    if batch_idx is not None:
+        out = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce=red)
+        cnt = torch.bincount(batch_idx, minlength=out.shape[0]).clamp(min=1).to(prop.dtype)
+        node_scale = torch.ones(N, device=prop.device) if red == "sum" else (1.0 / cnt)[batch_idx]
+    else:
+        out = prop.sum(0, keepdim=True) if red == "sum" else prop.mean(0, keepdim=True)
+        node_scale = torch.full((N,), 1.0 if red == "sum" else 1.0 / N, device=prop.device)
+    out = model.pp_layer(out, z, batch_idx, n_graphs)     # atomref / mean: no position dependence
+
+    # dense per-node scratch layout for the per-triplet dE/dcos
+    m_in = (ctx.in_ptr[1:] - ctx.in_ptr[:-1]).long()
+    m_out = (ctx.out_ptr[1:] - ctx.out_ptr[:-1]).long()
+    prod = m_in * m_out
+    tbase = (torch.cumsum(prod, 0) - prod).contiguous()
+    n_trip_dense = int(prod.sum().item())
+
+    forces = []
+    for i in range(model.out_size):
+        # E_i = sum_b out[b, i]: dE_i/dprop[n, j] = node_scale[n] * delta_ij
+        g_prop = torch.zeros_like(prop)
+        g_prop[:, i] = node_scale
+        g_b = ops.dense(g_prop, _t(lin[4].weight))
+        g_a = ops.dense(ops.act_bwd(g_b, pre_b, ACT), _t(lin[2].weight))
+        g_x = ops.dense(ops.act_bwd(g_a, pre_a, ACT), _t(lin[0].weight))
+        g_rb = torch.zeros_like(rb)
+        g_u_p = torch.zeros(ctx.n_edges, 3, device=pos.device)
+        for layer, sv in zip(reversed(model.int_layers), reversed(saved)):
+            g_x = layer_backward(layer, sv, g_x, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tbase, n_trip_dense, g_rb, g_u_p)
+        # x0 depends on z only.  Geometry: rb = R(dist), u = vec / dist, vec = pos[t] - pos[s] + shift @ lattice
+        g_u = torch.empty_like(g_u_p)
+        g_u[ctx.order.long()] = g_u_p                       # p-space -> caller's edge order
+        g_vec = ops.geometry_bwd(dist, uvec, g_rb, g_u, model.rbf.orb_table, model.rbf.rbf_kind,
+                                 model.rbf.cutoff_net.kind, model.cutoff)
+        g_vec_p = ops.gather_rows(g_vec, ctx.order)
+        g_pos = _in_sum(g_vec_p, ctx, N) - ops.segment_sum(g_vec_p, ctx.out_ptr)
+        forces.append(-g_pos)
+    force = forces[0] if model.out_size == 1 else torch.stack(forces, dim=1)
+    return out, force

@@ -472,9 +472,10 @@ class LCAONet(BaseMPNN):
         optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
         Inference only for now: no autograd graph is recorded (backward kernels: SURVEY.md §8f-3)."""
         if self.regress_forces and not self.direct_forces:
-            raise NotImplementedError(
-                "regress_forces with direct_forces=False needs -dE/dpos through the HIP kernels; their backward "
-                "pass is not built yet (SURVEY.md §8f-3)")
+            # F = -dE/dpos (lcaonet.py:310-317): species-pair forward + hand-written reverse sweep (model/forces.py)
+            from .forces import forward_with_autograd_forces
+
+            return forward_with_autograd_forces(self, graph)
         batch_idx = graph.get(GraphKeys.Batch_idx)
         z = graph[GraphKeys.Z]
         pos = graph[GraphKeys.Pos]
@@ -496,8 +497,6 @@ class LCAONet(BaseMPNN):
             # outputs; valid when cst comes from this model's own embedding in eval mode.
             if self.training or self.add_valence:
                 raise NotImplementedError("cst_mode='pair' needs eval mode and add_valence=False")
-            if self.emb_size_conv not in ops.FUSED_WIDTHS:
-                raise NotImplementedError(f"cst_mode='pair' is built for emb_size_conv in {ops.FUSED_WIDTHS}")
             x, cst, zdim = self.emb_layer.forward_pair_table(z)
             pair = (z, zdim)
         elif cst_mode != "edge":

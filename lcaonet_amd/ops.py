@@ -328,3 +328,71 @@ def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2):
     _call("lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg),
                                           _stream())
     return msg
+
+
+# --- activation-gradient kernels (autograd forces at inference; csrc/lcao_backward.hip) -------------------------
+def act_bwd(g, pre, act):
+    g, pre = _f32(g), _f32(pre)
+    out = torch.empty_like(g)
+    _call("lcao_act_bwd", _p(g), _p(pre), g.numel(), act, _p(out), _stream())
+    return out
+
+
+def pair_pre(Ps, Pt, src_p, dst_p):
+    Ps, Pt = _f32(Ps), _f32(Pt)
+    E, V = src_p.numel(), Ps.shape[1]
+    pre1 = torch.empty(E, V, device=Ps.device, dtype=torch.float32)
+    _call("lcao_pair_pre", _p(Ps), _p(Pt), _p(src_p), _p(dst_p), E, V, _p(pre1), _stream())
+    return pre1
+
+
+def message_bwd(g_agg, src_p, bw, pre2):
+    g_agg, bw, pre2 = _f32(g_agg), _f32(bw), _f32(pre2)
+    E, V = bw.shape
+    g_bw, g_pre2 = torch.empty_like(bw), torch.empty_like(bw)
+    _call("lcao_message_bwd", _p(g_agg), _p(src_p), _p(bw), _p(pre2), E, V, _p(g_bw), _p(g_pre2), _stream())
+    return g_bw, g_pre2
+
+
+def combine_bwd(g_lw, B, ft):
+    g_lw, B, ft = _f32(g_lw), _f32(B), _f32(ft)
+    E, V = B.shape
+    g_B, g_ft = torch.empty_like(B), torch.empty_like(B)
+    _call("lcao_combine_bwd", _p(g_lw), _p(B), _p(ft), E, V, _p(g_B), _p(g_ft), _stream())
+    return g_B, g_ft
+
+
+def triplet_bwd(g_tbw, Ag, gram, uvec_p, src_p, dst_p, in_ptr, in_pos, out_ptr, tbase, n_trip_dense, e_own, n_own):
+    g_tbw, Ag, gram, uvec_p = _f32(g_tbw), _f32(Ag), _f32(gram), _f32(uvec_p)
+    E, n_l, V = Ag.shape
+    dev = Ag.device
+    g_Ag = torch.zeros_like(Ag)          # edges that are in no owned in-list keep a zero gradient
+    g_gram = torch.zeros(E, 10, device=dev)
+    g_uq = torch.zeros(E, 3, device=dev)
+    g_up = torch.zeros(E, 3, device=dev)
+    gc = torch.empty(max(n_trip_dense, 1), device=dev, dtype=torch.float32)
+    n_in_total = E if n_own == out_ptr.numel() - 1 else 0   # single GPU: every edge is in exactly one in-list
+    _call("lcao_triplet_bwd", _p(g_tbw), _p(Ag), _p(gram), _p(uvec_p), _p(src_p), _p(dst_p), _p(in_ptr), _p(in_pos),
+          _p(out_ptr), _p(tbase), E, e_own, n_own, n_in_total, V, n_l, _p(g_Ag), _p(g_gram), _p(g_uq), _p(g_up), _p(gc),
+          _stream())
+    return g_Ag, g_gram, g_uq, g_up
+
+
+def pair_contract_bwd(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, e_own, n_l, zdim, g_rb):
+    Tf, rb, gate, g_Ag, g_B, g_gram = _f32(Tf), _f32(rb), _f32(gate), _f32(g_Ag), _f32(g_B), _f32(g_gram)
+    z = _i64(z)
+    E, D = rb.shape
+    V = Tf.shape[-1]
+    g_gate_part = torch.empty(E, V, device=rb.device, dtype=torch.float32)
+    _call("lcao_pair_contract_bwd", _p(Tf), _p(rb), _p(order), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate), _p(g_Ag),
+          _p(g_B), _p(g_gram), E, e_own, D, V, n_l, zdim, _p(g_rb), _p(g_gate_part), _stream())
+    return g_gate_part
+
+
+def geometry_bwd(dist, uvec, g_rb, g_u, orb_table, rbf_kind, cutoff_kind, rc):
+    dist, uvec, g_rb, g_u, orb_table = _f32(dist), _f32(uvec), _f32(g_rb), _f32(g_u), _f32(orb_table)
+    E, D = g_rb.shape
+    g_vec = torch.empty(E, 3, device=dist.device, dtype=torch.float32)
+    _call("lcao_geometry_bwd", _p(dist), _p(uvec), _p(g_rb), _p(g_u), E, D, _p(orb_table), RBF_KINDS[rbf_kind],
+          CUTOFF_KINDS[cutoff_kind], float(rc), _p(g_vec), _stream())
+    return g_vec

