@@ -203,6 +203,12 @@ int lcao_triplet_bwd(const float* g_tbw, const float* Ag, const float* gram, con
                      const int32_t* dst_p, const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr,
                      const int64_t* tbase, int64_t n_edges, int64_t e_own, int n_own, int64_t n_in_total, int V, int n_l,
                      float* g_Ag, float* g_gram, float* g_uq, float* g_up, float* gc_scratch, void* stream);
+/* the same reverse step as one fp32-MFMA kernel per centre node (V in {32,64,128}; every node a centre): writes g_Ag,
+ * g_gram, g_uq for every edge and g_up for every edge; no scratch */
+int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const float* gram, const float* uvec_p,
+                          const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr, int64_t n_nodes,
+                          int64_t n_edges, int V, int n_l, float* g_Ag, float* g_gram, float* g_uq, float* g_up,
+                          void* stream);
 int lcao_pair_contract_bwd(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d, const int64_t* z,
                            const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* g_Ag,
                            const float* g_B, const float* g_gram, int64_t n_edges, int64_t e_own, int n_orb, int V, int n_l,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "lcao_message_bwd": [P, P, P, P, L, I, P, P, P],
     "lcao_combine_bwd": [P, P, P, L, I, P, P, P],
     "lcao_triplet_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, I, L, I, I, P, P, P, P, P, P],
+    "lcao_triplet_bwd_mfma": [P, P, P, P, P, P, P, L, L, I, I, P, P, P, P, P],
     "lcao_pair_contract_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, P, P, P],
     "lcao_geometry_bwd": [P, P, P, P, L, I, P, I, I, F, P, P],
     "lcao_lds_bytes_coeff_mlp": [I, I, I],

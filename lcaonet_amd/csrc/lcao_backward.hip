@@ -159,15 +159,6 @@ extern "C" int lcao_combine_bwd(const float* g_lw, const float* B, const float* 
 // g_c = dE/dc goes to the dense per-node scratch gc[tbase[s] + j * m_out + i] (j = index of q in In(s), i = index of p
 // in Out(s)) so that a second kernel can form g_u[p] = sum_q g_c u_q without atomics.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lcao_y_l0_grad(float c, int l) {
-  switch (l) {
-    case 0: return 0.0f;
-    case 1: return 0.48860251190292f;
-    case 2: return 2.0f * 0.94617469575756f * c;
-    default: return 0.373176332590115f * (15.0f * c * c - 3.0f);
-  }
-}
-
 template <int R>
 __global__ void k_triplet_bwd_q(const float* __restrict__ g_tbw, const float* __restrict__ Ag,
                                 const float* __restrict__ gram, const float* __restrict__ uvec_p,
@@ -406,6 +397,90 @@ __global__ void k_pair_contract_bwd(const float* __restrict__ Tf, const float* _
   }
 }
 
+// fast form for V in {32, 64, 128}: 16 lanes per edge (4 edges per wave), float4 channel chunks, DPP row reductions
+template <int V, int NL>
+__global__ __launch_bounds__(256) void k_pair_contract_bwd16(
+    const float* __restrict__ Tf, const float* __restrict__ rb, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ l_of_d, const int64_t* __restrict__ z, const int32_t* __restrict__ src_p,
+    const int32_t* __restrict__ dst_p, const float* __restrict__ gate, const float* __restrict__ g_Ag,
+    const float* __restrict__ g_B, const float* __restrict__ g_gram, int64_t E, int64_t e_own, int D, int zdim,
+    float* __restrict__ g_rb, float* __restrict__ g_gate_part) {
+  constexpr int NC = (V + 63) / 64;
+  const int sub = threadIdx.x & 15, rowi = (threadIdx.x & 63) >> 4;
+  int64_t p0 = ((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) * 4;
+  const int64_t stride = (((int64_t)gridDim.x * blockDim.x) >> 6) * 4;
+  for (; p0 < E; p0 += stride) {
+    const int64_t p = p0 + rowi;
+    const bool valid = p < E;
+    const int64_t pc = valid ? p : E - 1;
+    const int64_t e = order ? order[pc] : pc;
+    const int s = src_p[pc];
+    const int64_t pair = z[s] * zdim + z[dst_p[pc]];
+    const float* t = Tf + pair * (int64_t)D * V + 4 * sub;
+    f32x4 a[NL][NC], gA[NL][NC];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d) {
+      const float w = rb[e * D + d];
+      const int l = l_of_d[d];
+#pragma unroll
+      for (int ll = 0; ll < NL; ++ll)
+        if (l == ll) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            if ((64 * c + 4 * sub) < V) a[ll][c] += w * *(const f32x4*)(t + d * V + 64 * c);
+        }
+    }
+    float gG[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) gG[i] = g_gram[pc * 10 + i];
+    const bool own = pc < e_own;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool chv = (64 * c + 4 * sub) < V;
+      const int64_t off = 64 * c + 4 * sub;
+      const f32x4 gt = chv ? *(const f32x4*)(gate + (int64_t)s * V + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 gb = (own && chv) ? *(const f32x4*)(g_B + pc * V + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 gpart = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 gag[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        gag[l] = chv ? *(const f32x4*)(g_Ag + (pc * NL + l) * V + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        gpart += gag[l] * a[l][c];
+      }
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        f32x4 v = gag[l] * gt + gb;
+#pragma unroll
+        for (int l2 = 0; l2 < NL; ++l2) {
+          const int lo = l < l2 ? l : l2, hi = l < l2 ? l2 : l;
+          v += (gG[lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo)] * (l == l2 ? 2.0f : 1.0f)) * a[l2][c];
+        }
+        gA[l][c] = v;
+      }
+      if (valid && chv) *(f32x4*)(g_gate_part + p * V + off) = gpart;
+    }
+    for (int d = 0; d < D; ++d) {
+      const int l = l_of_d[d];
+      float acc = 0.f;
+#pragma unroll
+      for (int ll = 0; ll < NL; ++ll)
+        if (l == ll) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            if ((64 * c + 4 * sub) < V) {
+              const f32x4 tv = *(const f32x4*)(t + d * V + 64 * c);
+              acc += gA[ll][c][0] * tv[0] + gA[ll][c][1] * tv[1] + gA[ll][c][2] * tv[2] + gA[ll][c][3] * tv[3];
+            }
+        }
+      acc = lcao_row16_sum(acc);
+      if (valid && sub == 0) g_rb[e * D + d] += acc;
+    }
+  }
+}
+
 extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
                                       const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
                                       const float* g_Ag, const float* g_B, const float* g_gram, int64_t n_edges,
@@ -420,6 +495,16 @@ extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const in
   LCAO_CHECK_PTR(g_rb); LCAO_CHECK_PTR(g_gate_part);
   dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
   hipStream_t st = (hipStream_t)stream;
+#define PB16(V_, NL_)                                                                                                  \
+  if (V == V_ && n_l == NL_) {                                                                                         \
+    hipLaunchKernelGGL((k_pair_contract_bwd16<V_, NL_>), dim3(lcao_blocks(n_edges, 16, 65536)), block, 0, st, Tf, rb, order, \
+                       l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, n_edges, e_own, n_orb, zdim, g_rb, g_gate_part); \
+    return lcao_launch_status();                                                                                       \
+  }
+#define PB16V(V_) PB16(V_, 1) PB16(V_, 2) PB16(V_, 3) PB16(V_, 4)
+  PB16V(128) PB16V(64) PB16V(32)
+#undef PB16V
+#undef PB16
   int R = (V + 63) / 64;
 #define PB_LAUNCH(RR)                                                                                                 \
   hipLaunchKernelGGL(k_pair_contract_bwd<RR>, grid, block, 0, st, Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, \

@@ -55,6 +55,16 @@ __device__ __forceinline__ float lcao_y_l0(float c, int l) {
   }
 }
 
+// d/dc of Y_l^0(c)
+__device__ __forceinline__ float lcao_y_l0_grad(float c, int l) {
+  switch (l) {
+    case 0: return 0.0f;
+    case 1: return 0.48860251190292f;
+    case 2: return 2.0f * 0.94617469575756f * c;
+    default: return 0.373176332590115f * (15.0f * c * c - 3.0f);
+  }
+}
+
 // radial cutoff envelopes (lcaonet/nn/cutoff.py:32-34, 41-43, 62-67).  The envelope cancels catastrophically
 // towards rc, so its rounding pattern IS the result there: each power is a correctly rounded
 // pow (as torch's x**k), each product and sum is rounded separately (no FMA contraction), in the reference's order.

@@ -950,3 +950,191 @@ extern "C" int lcao_triplet_gemm(const float* Ag, const float* gram, const float
   }
   return lcao_launch_status();
 }
+
+// ===================================================================================================
+// lcao_triplet_bwd (MFMA form) — reverse of lcao_triplet_gemm for one centre node per wave.
+//   forward:  tbw[p,:] = sum_{q in In(s), q != p} sum_l w_pql Ag[q,l,:],   w_pql = Y_l(c_pq) / max(sqrt(Y^T G_q Y), eps)
+//   reverse:  GW[p,q,l] = g_tbw[p,:] . Ag[q,l,:]                    (GEMM 1: out-edges x (in-edges, l), k = channels)
+//             scalar chain per (p,q): g_c = dE/dc_pq, g_gram[q] += ..., w_pql                     (registers)
+//             g_Ag[q,l,:] = sum_p w_pql g_tbw[p,:]                   (GEMM 2: channels x in-edges, k = out-edges)
+//             g_uq[q] = sum_p g_c u_p   (in-edge side),   g_up[p] = sum_q g_c u_q   (out-edge side)
+// Tiles of 16 in-edges (columns, on the lane) x 16 out-edges (rows, in the 4 registers x 4 quarters).  GEMM 1 leaves
+// (p = 4*quarter + r, q = lane & 15) in lane (q, quarter) register r for every l — which is the B-operand layout of
+// GEMM 2 when its k-step r takes p = 4*quarter + r from quarter `quarter`.  The wave owns every output row it writes
+// (each edge is an in-edge of exactly one node, an out-edge of exactly one node): no atomics.
+// ===================================================================================================
+template <int V, int NL>
+__global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
+    const float* __restrict__ g_tbw, const float* __restrict__ Ag, const float* __restrict__ gram,
+    const float* __restrict__ uvec_p, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_pos,
+    const int32_t* __restrict__ out_ptr, int n_nodes, float* __restrict__ g_Ag, float* __restrict__ g_gram,
+    float* __restrict__ g_uq, float* __restrict__ g_up) {
+  constexpr int KT = V / 16;   // k chunks of GEMM 1 = channel tiles of GEMM 2
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, quarter = lane >> 4;
+  for (int s = blockIdx.x * 4 + wave; s < n_nodes; s += gridDim.x * 4) {
+    const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
+    const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
+    // g_up of this node's out-edges accumulates over in-tiles in global memory (this wave is its only writer)
+    // (zeroed by the very lanes that later add into it: same-lane program order is the only ordering relied upon)
+    for (int it0 = 0; it0 < m_out; it0 += 16)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pi = it0 + 4 * quarter + r;
+        if (n == 0 && pi < m_out) {
+          float* o = g_up + 3 * (int64_t)(p0 + pi);
+          o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+        }
+      }
+    for (int jt = 0; jt < m_in; jt += 16) {
+      const bool qv = (jt + n) < m_in;
+      const int q = in_pos[j0 + (qv ? jt + n : 0)];
+      const float qx = uvec_p[3 * (int64_t)q], qy = uvec_p[3 * (int64_t)q + 1], qz = uvec_p[3 * (int64_t)q + 2];
+      float G[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) G[i] = gram[(int64_t)q * 10 + i];
+      f32x4v gA[NL][KT];
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) gA[l][t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      float gG[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) gG[i] = 0.f;
+      float gqx = 0.f, gqy = 0.f, gqz = 0.f;
+      const float* agq = Ag + (int64_t)q * NL * V + 4 * quarter;
+
+      for (int it = 0; it < m_out; it += 16) {
+        asm volatile("" ::: "memory");
+        // ---- GEMM 1: gw[l][r] = g_tbw[p_(4*quarter+r)] . Ag[q_n, l]   (A operand: row = out-edge n, B: col = in-edge n)
+        const int pa = p0 + min(it + n, m_out - 1);
+        const float* gta = g_tbw + (int64_t)pa * V + 4 * quarter;
+        f32x4v gw[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) gw[l] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < KT; ++a) {
+          const f32x4v xa = *(const f32x4v*)(gta + 16 * a);
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            const f32x4v xb = *(const f32x4v*)(agq + l * V + 16 * a);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) gw[l] = MFMA16(xa[b], xb[b], gw[l]);
+          }
+        }
+        // ---- scalar chain for this lane's 4 pairs (p = it + 4*quarter + r, q)
+        float w[NL][4];
+        float gpx[4], gpy[4], gpz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pi = it + 4 * quarter + r;
+          const int p = p0 + min(pi, m_out - 1);
+          const bool ok = qv && pi < m_out && p != q;
+          const float px = uvec_p[3 * (int64_t)p], py = uvec_p[3 * (int64_t)p + 1], pz = uvec_p[3 * (int64_t)p + 2];
+          const float c = px * qx + py * qy + pz * qz;
+          float y[4], dy[4], GY[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int l = 0; l < 4; ++l) { y[l] = l < NL ? lcao_y_l0(c, l) : 0.f; dy[l] = l < NL ? lcao_y_l0_grad(c, l) : 0.f; }
+          float m = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int l2 = l; l2 < NL; ++l2) {
+              const float gv = G[gram_idx(l, l2)];
+              if (l == l2) { m += y[l] * y[l] * gv; GY[l] += gv * y[l]; }
+              else { m += 2.0f * y[l] * y[l2] * gv; GY[l] += gv * y[l2]; GY[l2] += gv * y[l]; }
+            }
+          const float mc = fmaxf(m, 0.f);
+          const bool live = mc > 1e-24f;
+          const float inv = live ? __builtin_amdgcn_rsqf(mc) : 1e12f;
+          float g_inv = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) g_inv += gw[l][r] * y[l];
+          const float g_m = (ok && live) ? -0.5f * g_inv * inv * inv * inv : 0.f;
+          float gcv = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) gcv += (gw[l][r] * inv + 2.0f * g_m * GY[l]) * dy[l];
+          gcv = ok ? gcv : 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            w[l][r] = ok ? y[l] * inv : 0.f;
+#pragma unroll
+            for (int l2 = l; l2 < NL; ++l2) gG[gram_idx(l, l2)] += g_m * (l == l2 ? y[l] * y[l] : 2.0f * y[l] * y[l2]);
+          }
+          gqx += gcv * px; gqy += gcv * py; gqz += gcv * pz;
+          gpx[r] = gcv * qx; gpy[r] = gcv * qy; gpz[r] = gcv * qz;
+        }
+        // g_up[p] += sum over the 16 in-edges of this tile (lanes n within each 16-lane row), one writer lane per row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sx = lcao_row16_sum(gpx[r]), sy = lcao_row16_sum(gpy[r]), sz = lcao_row16_sum(gpz[r]);
+          const int pi = it + 4 * quarter + r;
+          if (n == 0 && pi < m_out) {
+            float* o = g_up + 3 * (int64_t)(p0 + pi);
+            o[0] += sx; o[1] += sy; o[2] += sz;
+          }
+        }
+        // ---- GEMM 2: gA[l][t] (channel 16t + 4*quarter + r', in-edge n) += sum_p g_tbw[p][channel] w[l][p, q_n]
+        //      k-step r: quarter `quarter` contributes p = it + 4*quarter + r (B operand = w[l][r])
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pr = p0 + min(it + 4 * quarter + r, m_out - 1);
+          const float* gtr = g_tbw + (int64_t)pr * V + n;
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            const float av = gtr[16 * t];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) gA[l][t] = MFMA16(av, w[l][r], gA[l][t]);
+          }
+        }
+      }
+      // ---- this in-tile is complete: reduce the per-lane partials over the four quarters, write the rows of q
+#pragma unroll
+      for (int i = 0; i < 10; ++i) { gG[i] += __shfl_xor(gG[i], 16); gG[i] += __shfl_xor(gG[i], 32); }
+      gqx += __shfl_xor(gqx, 16); gqx += __shfl_xor(gqx, 32);
+      gqy += __shfl_xor(gqy, 16); gqy += __shfl_xor(gqy, 32);
+      gqz += __shfl_xor(gqz, 16); gqz += __shfl_xor(gqz, 32);
+      if (qv) {
+        if (quarter == 0) {
+#pragma unroll
+          for (int i = 0; i < 10; ++i) g_gram[(int64_t)q * 10 + i] = gG[i];
+          g_uq[3 * (int64_t)q] = gqx; g_uq[3 * (int64_t)q + 1] = gqy; g_uq[3 * (int64_t)q + 2] = gqz;
+        }
+        float* go = g_Ag + (int64_t)q * NL * V + 4 * quarter;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int t = 0; t < KT; ++t) *(f32x4v*)(go + l * V + 16 * t) = gA[l][t];
+      }
+    }
+  }
+}
+
+extern "C" int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const float* gram, const float* uvec_p,
+                                     const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr,
+                                     int64_t n_nodes, int64_t n_edges, int V, int n_l, float* g_Ag, float* g_gram,
+                                     float* g_uq, float* g_up, void* stream) {
+  LCAO_CHECK_SIZE(n_nodes);
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
+  if (n_edges == 0 || n_nodes == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_tbw); LCAO_CHECK_PTR(Ag); LCAO_CHECK_PTR(gram); LCAO_CHECK_PTR(uvec_p); LCAO_CHECK_PTR(in_ptr);
+  LCAO_CHECK_PTR(in_pos); LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(g_Ag); LCAO_CHECK_PTR(g_gram); LCAO_CHECK_PTR(g_uq);
+  LCAO_CHECK_PTR(g_up);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t groups = (n_nodes + 3) / 4;
+  int64_t cap = (int64_t)lcao_num_cu() * 8;
+  if (groups > cap) groups = cap;
+#define TBM_CASE(V_, NL_)                                                                                          \
+  if (V == V_ && n_l == NL_) {                                                                                     \
+    hipLaunchKernelGGL((k_triplet_bwd_mfma<V_, NL_>), dim3((unsigned)groups), dim3(256), 0, st, g_tbw, Ag, gram, uvec_p, \
+                       in_ptr, in_pos, out_ptr, (int)n_nodes, g_Ag, g_gram, g_uq, g_up);                           \
+    return lcao_launch_status();                                                                                   \
+  }
+#define TBM_V(V_) TBM_CASE(V_, 1) TBM_CASE(V_, 2) TBM_CASE(V_, 3) TBM_CASE(V_, 4)
+  TBM_V(128) TBM_V(64) TBM_V(32)
+#undef TBM_V
+#undef TBM_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}

@@ -362,10 +362,20 @@ def combine_bwd(g_lw, B, ft):
     return g_B, g_ft
 
 
-def triplet_bwd(g_tbw, Ag, gram, uvec_p, src_p, dst_p, in_ptr, in_pos, out_ptr, tbase, n_trip_dense, e_own, n_own):
+def triplet_bwd(g_tbw, Ag, gram, uvec_p, src_p, dst_p, in_ptr, in_pos, out_ptr, tbase, n_trip_dense, e_own, n_own,
+                mfma: bool | None = None):
     g_tbw, Ag, gram, uvec_p = _f32(g_tbw), _f32(Ag), _f32(gram), _f32(uvec_p)
     E, n_l, V = Ag.shape
     dev = Ag.device
+    all_centres = (n_own == out_ptr.numel() - 1) and e_own == E
+    if mfma is None:
+        mfma = V in FUSED_WIDTHS and all_centres
+    if mfma:
+        g_Ag, g_gram = torch.empty_like(Ag), torch.empty(E, 10, device=dev)
+        g_uq, g_up = torch.empty(E, 3, device=dev), torch.empty(E, 3, device=dev)
+        _call("lcao_triplet_bwd_mfma", _p(g_tbw), _p(Ag), _p(gram), _p(uvec_p), _p(in_ptr), _p(in_pos), _p(out_ptr), n_own,
+              E, V, n_l, _p(g_Ag), _p(g_gram), _p(g_uq), _p(g_up), _stream())
+        return g_Ag, g_gram, g_uq, g_up
     g_Ag = torch.zeros_like(Ag)          # edges that are in no owned in-list keep a zero gradient
     g_gram = torch.zeros(E, 10, device=dev)
     g_uq = torch.zeros(E, 3, device=dev)
