@@ -212,7 +212,12 @@ int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const float* gram
 int lcao_pair_contract_bwd(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d, const int64_t* z,
                            const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* g_Ag,
                            const float* g_B, const float* g_gram, int64_t n_edges, int64_t e_own, int n_orb, int V, int n_l,
-                           int zdim, float* g_rb /* accumulated */, float* g_gate_part, void* stream);
+                           int zdim, float* g_rb /* accumulated */, float* g_gate_part,
+                           float* g_A_out /* (E,n_l,V) or NULL */, void* stream);
+/* training: partial (n_chunks, D, V) sums of rb[e,d] * g_A[p,l(d),:] over chunks of the pair-sorted edge list */
+int lcao_pair_table_grad(const float* g_A, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                         const int32_t* perm, const int32_t* chunk_ptr, int64_t n_chunks, int n_orb, int V, int n_l,
+                         float* partial, void* stream);
 int lcao_geometry_bwd(const float* dist, const float* uvec, const float* g_rb, const float* g_u, int64_t n_edges, int n_orb,
                       const float* orb_table, int rbf_kind, int cutoff_kind, float rc, float* g_vec, void* stream);
 

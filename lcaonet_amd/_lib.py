@@ -47,7 +47,8 @@ SIGNATURES = {
     "lcao_combine_bwd": [P, P, P, L, I, P, P, P],
     "lcao_triplet_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, I, L, I, I, P, P, P, P, P, P],
     "lcao_triplet_bwd_mfma": [P, P, P, P, P, P, P, L, L, I, I, P, P, P, P, P],
-    "lcao_pair_contract_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, P, P, P],
+    "lcao_pair_contract_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, P, P, P, P],
+    "lcao_pair_table_grad": [P, P, P, P, P, P, L, I, I, I, P, P],
     "lcao_geometry_bwd": [P, P, P, P, L, I, P, I, I, F, P, P],
     "lcao_lds_bytes_coeff_mlp": [I, I, I],
     "lcao_debug_set_clock_probe": [P],

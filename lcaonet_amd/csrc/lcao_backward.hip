@@ -331,7 +331,8 @@ __global__ void k_pair_contract_bwd(const float* __restrict__ Tf, const float* _
                                     const int32_t* __restrict__ dst_p, const float* __restrict__ gate,
                                     const float* __restrict__ g_Ag, const float* __restrict__ g_B,
                                     const float* __restrict__ g_gram, int64_t E, int64_t e_own, int D, int V, int NL,
-                                    int zdim, float* __restrict__ g_rb, float* __restrict__ g_gate_part) {
+                                    int zdim, float* __restrict__ g_rb, float* __restrict__ g_gate_part,
+                                    float* __restrict__ g_A_out) {
   int lane = threadIdx.x & 63;
   int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -378,6 +379,7 @@ __global__ void k_pair_contract_bwd(const float* __restrict__ Tf, const float* _
           v += gs * a[l2][r];
         }
         gA[l][r] = v;
+        if (g_A_out && l < NL && ch < V) g_A_out[(p * NL + l) * V + ch] = v;
       }
       if (ch < V) g_gate_part[p * V + ch] = gpart;
     }
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256) void k_pair_contract_bwd16(
     const int32_t* __restrict__ l_of_d, const int64_t* __restrict__ z, const int32_t* __restrict__ src_p,
     const int32_t* __restrict__ dst_p, const float* __restrict__ gate, const float* __restrict__ g_Ag,
     const float* __restrict__ g_B, const float* __restrict__ g_gram, int64_t E, int64_t e_own, int D, int zdim,
-    float* __restrict__ g_rb, float* __restrict__ g_gate_part) {
+    float* __restrict__ g_rb, float* __restrict__ g_gate_part, float* __restrict__ g_A_out) {
   constexpr int NC = (V + 63) / 64;
   const int sub = threadIdx.x & 15, rowi = (threadIdx.x & 63) >> 4;
   int64_t p0 = ((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) * 4;
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(256) void k_pair_contract_bwd16(
           v += (gG[lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo)] * (l == l2 ? 2.0f : 1.0f)) * a[l2][c];
         }
         gA[l][c] = v;
+        if (g_A_out && valid && chv) *(f32x4*)(g_A_out + (p * NL + l) * V + off) = v;
       }
       if (valid && chv) *(f32x4*)(g_gate_part + p * V + off) = gpart;
     }
@@ -485,7 +488,7 @@ extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const in
                                       const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
                                       const float* g_Ag, const float* g_B, const float* g_gram, int64_t n_edges,
                                       int64_t e_own, int n_orb, int V, int n_l, int zdim, float* g_rb,
-                                      float* g_gate_part, void* stream) {
+                                      float* g_gate_part, float* g_A_out, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   if (n_orb <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0) return LCAO_ERR_INVALID;
   if (V > 512) return LCAO_ERR_UNSUPPORTED;
@@ -498,7 +501,7 @@ extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const in
 #define PB16(V_, NL_)                                                                                                  \
   if (V == V_ && n_l == NL_) {                                                                                         \
     hipLaunchKernelGGL((k_pair_contract_bwd16<V_, NL_>), dim3(lcao_blocks(n_edges, 16, 65536)), block, 0, st, Tf, rb, order, \
-                       l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, n_edges, e_own, n_orb, zdim, g_rb, g_gate_part); \
+                       l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, n_edges, e_own, n_orb, zdim, g_rb, g_gate_part, g_A_out); \
     return lcao_launch_status();                                                                                       \
   }
 #define PB16V(V_) PB16(V_, 1) PB16(V_, 2) PB16(V_, 3) PB16(V_, 4)
@@ -508,7 +511,7 @@ extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const in
   int R = (V + 63) / 64;
 #define PB_LAUNCH(RR)                                                                                                 \
   hipLaunchKernelGGL(k_pair_contract_bwd<RR>, grid, block, 0, st, Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, \
-                     g_gram, n_edges, e_own, n_orb, V, n_l, zdim, g_rb, g_gate_part)
+                     g_gram, n_edges, e_own, n_orb, V, n_l, zdim, g_rb, g_gate_part, g_A_out)
   if (R == 1) PB_LAUNCH(1);
   else if (R == 2) PB_LAUNCH(2);
   else if (R <= 4) PB_LAUNCH(4);
@@ -585,5 +588,70 @@ extern "C" int lcao_geometry_bwd(const float* dist, const float* uvec, const flo
   LCAO_CHECK_PTR(g_vec);
   hipLaunchKernelGGL(k_geometry_bwd, dim3(lcao_blocks(n_edges, 256)), dim3(256), 0, (hipStream_t)stream, dist, uvec, g_rb,
                      g_u, n_edges, n_orb, orb_table, rbf_kind, cutoff_kind, rc, g_vec);
+  return lcao_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// gradient of the species-pair table (training):  A[p,l,:] = sum_{d in l} rb[e,d] Tf[pair(p),d,:]  =>
+//   g_Tf[pair,d,:] = sum_{p: pair(p) = pair} rb[e,d] g_A[p,l(d),:]
+// Edges are visited sorted by pair id (perm); every pair's list is cut into chunks of <= 256 edges (chunk_ptr over the
+// sorted list, chunks never span pairs); one wave per chunk writes a partial (D, V) table; the caller sums each pair's
+// partials in order (lcao_segment_sum) — deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ void k_pair_table_grad(const float* __restrict__ g_A, const float* __restrict__ rb,
+                                  const int32_t* __restrict__ order, const int32_t* __restrict__ l_of_d,
+                                  const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_ptr,
+                                  int64_t n_chunks, int D, int V, int NL, float* __restrict__ partial) {
+  int lane = threadIdx.x & 63;
+  int64_t c = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; c < n_chunks; c += nwave) {
+    const int i0 = chunk_ptr[c], i1 = chunk_ptr[c + 1];
+    for (int d = 0; d < D; ++d) {
+      const int l = l_of_d[d];
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      for (int i = i0; i < i1; ++i) {
+        const int p = perm[i];
+        const int64_t e = order ? order[p] : p;
+        const float w = rb[e * D + d];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          if (ch < V) acc[r] += w * g_A[((int64_t)p * NL + l) * V + ch];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ch = lane + 64 * r;
+        if (ch < V) partial[(c * D + d) * V + ch] = acc[r];
+      }
+    }
+  }
+}
+
+extern "C" int lcao_pair_table_grad(const float* g_A, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                                    const int32_t* perm, const int32_t* chunk_ptr, int64_t n_chunks, int n_orb, int V,
+                                    int n_l, float* partial, void* stream) {
+  LCAO_CHECK_SIZE(n_chunks);
+  if (n_orb <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  if (n_chunks == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_A); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(perm); LCAO_CHECK_PTR(chunk_ptr);
+  LCAO_CHECK_PTR(partial);
+  dim3 grid(lcao_blocks(n_chunks, 4, 65536)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  int R = (V + 63) / 64;
+#define PTG(RR)                                                                                                      \
+  hipLaunchKernelGGL(k_pair_table_grad<RR>, grid, block, 0, st, g_A, rb, order, l_of_d, perm, chunk_ptr, n_chunks, n_orb, \
+                     V, n_l, partial)
+  if (R == 1) PTG(1);
+  else if (R == 2) PTG(2);
+  else if (R <= 4) PTG(4);
+  else PTG(8);
+#undef PTG
   return lcao_launch_status();
 }

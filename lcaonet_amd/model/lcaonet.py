@@ -465,12 +465,26 @@ class LCAONet(BaseMPNN):
         return out
 
     # --- forward ------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
-                trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge"):
+                trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
+                differentiable: bool | None = None):
         """graph: PyG-Batch-like object with z, pos, edge_index [centre, neighbour], edge_shift, lattice and
         optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
-        Inference only for now: no autograd graph is recorded (backward kernels: SURVEY.md §8f-3)."""
+
+        differentiable (default: `self.training and torch.is_grad_enabled()`): record an autograd graph to every
+        parameter (model/train.py: HIP forward + hand-written HIP backward of the interaction stack).  Otherwise the
+        inference pipeline runs and the result carries no graph."""
+        if differentiable is None:
+            differentiable = self.training and torch.is_grad_enabled()
+        if differentiable:
+            from .train import forward_differentiable
+
+            return forward_differentiable(self, graph)
+        return self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode)
+
+    @torch.no_grad()
+    def _forward_inference(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
+                           trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge"):
         if self.regress_forces and not self.direct_forces:
             # F = -dE/dpos (lcaonet.py:310-317): species-pair forward + hand-written reverse sweep (model/forces.py)
             from .forces import forward_with_autograd_forces

@@ -1,0 +1,289 @@
+"""Differentiable forward (training): parameter gradients of LCAONet through the HIP kernels.
+
+Structure (all of it is exact, summation order aside):
+  * Everything the embedding computes is a function of the atomic number (node vectors) or of the species pair
+    (coefficient vectors, embed.py:246-249) — including BatchNorm in TRAIN mode, whose batch statistics over N nodes /
+    E edges are count-weighted statistics over <= max_z species / (max_z+1)^2 pairs.  Those tiny table computations
+    (embeddings, f_z, f_e, both BatchNorms, and f_coeffs of every layer on the ~1.4 k-row pair table) run as ordinary
+    torch ops under autograd.
+  * The L interaction layers on N nodes / E edges — the hot path — are ONE torch.autograd.Function.  Its forward is the
+    pair-table HIP pipeline of model/lcaonet.py; its backward is the reverse sweep of model/forces.py extended with
+    weight gradients.  Weight-gradient products G^T X are plain GEMMs and go through the vendor library (torch.mm).
+  * The output heads (N-level MLPs) and the per-graph reduction are torch ops under autograd.
+Not built: double backward (training on autograd forces, create_graph=True) and add_valence.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import ops
+from ..data.keys import GraphKeys
+from ..nn.base import Dense
+from ..nn.scatter import csr_ptr
+
+ACT = ops.ACT_SILU
+PER_LAYER = ("node_weight.weight", "node_weight.bias", "f_three.0.weight", "basis_weight.weight", "f_node.0.weight",
+             "f_node.0.bias", "f_node.2.weight", "f_node.2.bias", "out_weight.weight")
+
+
+def _mlp(seq: nn.Sequential, x: Tensor) -> Tensor:
+    """nn.Sequential of Dense / activation modules as plain torch ops (autograd-visible); used on species tables only."""
+    for m in seq:
+        x = F.linear(x, m.weight, m.bias) if isinstance(m, Dense) else m(x)
+    return x
+
+
+def _bn_weighted(bn: nn.BatchNorm1d, h: Tensor, w: Tensor, n_samples: int, training: bool) -> Tensor:
+    """BatchNorm1d over a population in which table row r occurs with relative frequency w[r] (sum w = 1):
+    identical to applying the module to the expanded (n_samples, F) tensor, running-stat update included."""
+    if training:
+        mean = (w.unsqueeze(1) * h).sum(0)
+        var = (w.unsqueeze(1) * (h - mean) ** 2).sum(0)
+        with torch.no_grad():
+            if bn.track_running_stats:
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.running_mean.mul_(1 - mom).add_(mom * mean)
+                bn.running_var.mul_(1 - mom).add_(mom * var * (n_samples / max(n_samples - 1, 1)))
+                bn.num_batches_tracked += 1
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    return (h - mean) / torch.sqrt(var + bn.eps) * bn.weight + bn.bias
+
+
+def species_tables_autograd(model, z: Tensor, idx_s: Tensor, idx_t: Tensor):
+    """x_tab (max_z+1, H) and cst_pair ((max_z+1)^2, D, C), differentiable w.r.t. every embedding parameter."""
+    emb = model.emb_layer
+    dev = z.device
+    Z = emb.max_z
+    zz = torch.arange(1, Z + 1, device=dev)
+    z_embed = emb.z_embed(zz)
+    node_z, coeff_z = torch.split(z_embed, [emb.emb_size, emb.emb_size_coeff], dim=-1)
+    e_embed = emb.e_embed(zz)
+    D = e_embed.shape[1]
+    if emb.use_elec:
+        node_e, coeff_e = torch.split(e_embed, [emb.emb_size_node_e, emb.emb_size_coeff], dim=-1)
+        node_in = torch.cat([node_z, node_e.sum(1) / math.sqrt(D)], dim=-1)
+    else:
+        coeff_e, node_in = e_embed, node_z
+    zd = Z + 1
+    N, E = z.numel(), idx_s.numel()
+    cnt_z = torch.zeros(zd, device=dev).scatter_add_(0, z, torch.ones(N, device=dev))
+    pair = z[idx_s] * zd + z[idx_t]
+    cnt_p = torch.zeros(zd * zd, device=dev).scatter_add_(0, pair, torch.ones(E, device=dev))
+    # node table
+    h = _mlp(emb.node_embed.f_enc, node_in)                                    # (Z, H)
+    x_tab = _bn_weighted(emb.node_embed.bn, h, cnt_z[1:] / N, N, model.training)
+    x_tab = torch.cat([torch.zeros_like(x_tab[:1]), x_tab], dim=0)
+    # pair table
+    ce = emb.coeff_embed
+    C = emb.emb_size_coeff
+    wz = ce.f_z[0].weight
+    U, Vt = F.linear(coeff_z, wz[:, :C]), F.linear(coeff_z, wz[:, C:])          # (Z, C) each
+    fe = _mlp(ce.f_e, coeff_e)                                                   # (Z, D, C)
+    raw = fe.unsqueeze(0) * (1.0 + U.unsqueeze(1).unsqueeze(2) + Vt.unsqueeze(0).unsqueeze(2))   # (Zs, Zt, D, C)
+    wp = (cnt_p.view(zd, zd)[1:, 1:] / max(E, 1)).reshape(-1)
+    cst = _bn_weighted(ce.bn, raw.reshape(Z * Z, D * C), wp, E, model.training).reshape(Z, Z, D, C)
+    cst_pair = torch.cat([torch.zeros(1, zd, D, C, device=dev),
+                          torch.cat([torch.zeros(Z, 1, D, C, device=dev), cst], dim=1)], dim=0)
+    return x_tab, cst_pair.reshape(zd * zd, D, C), pair, zd
+
+
+class _Geom:
+    """Static (non-differentiated) per-forward data handed to the autograd Function."""
+
+    def __init__(self, model, graph):
+        from .base import BaseMPNN
+        from .lcaonet import EdgeContext
+
+        z = graph[GraphKeys.Z]
+        self.z = z
+        self.N = z.numel()
+        self.ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], self.N)
+        graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
+        self.dist, self.uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
+        self.uvec_p = self.ctx.uvec_p(self.uvec)
+        self.rb = model.rbf(self.dist)
+        self.l_of_d, self.n_l = model.shbf.l_of_d, model.n_l
+        # nodes grouped by species (gradient of the x_tab gather)
+        self.order_z = torch.argsort(z, stable=True)
+        self.ptr_z = csr_ptr(z[self.order_z], model.emb_layer.max_z + 1)
+
+    def pair_lists(self, pair: Tensor, zd: int, chunk: int = 256):
+        """p-space edges sorted by species pair, cut into chunks of <= `chunk` edges that never span two pairs."""
+        ctx = self.ctx
+        pair_p = pair[ctx.order.long()]
+        perm = torch.argsort(pair_p, stable=True)
+        ptr = csr_ptr(pair_p[perm], zd * zd).long()
+        n_chunks = (ptr[1:] - ptr[:-1] + chunk - 1) // chunk
+        cptr = torch.zeros(zd * zd + 1, dtype=torch.long, device=pair.device)
+        cptr[1:] = torch.cumsum(n_chunks, 0)
+        total = (pair.numel() + chunk - 1) // chunk + zd * zd             # static upper bound, no sync
+        cid = torch.arange(total + 1, device=pair.device)
+        seg = torch.searchsorted(cptr[1:], cid, right=True).clamp(max=zd * zd - 1)
+        lo = torch.minimum(ptr[seg] + (cid - cptr[seg]) * chunk, ptr[seg + 1])
+        lo = torch.where(cid < cptr[-1], lo, ptr[-1].expand_as(lo))
+        self.perm_pair = perm.to(torch.int32)
+        self.chunk_ptr = torch.cat([lo[:total], ptr[-1:]]).to(torch.int32)
+        self.pair_cptr = torch.clamp(cptr, max=total).to(torch.int32)
+        self.zd = zd
+
+
+def _mm_t(g: Tensor, x: Tensor) -> Tensor:
+    """weight gradient of y = x W^T:  dW = g^T x  (plain GEMM through the vendor library)."""
+    return torch.mm(g.t(), x)
+
+
+class LCAOStackFn(torch.autograd.Function):
+    """x_L = interaction_L(... interaction_1(x_tab[z]; Tf_1) ...; Tf_L) with hand-written HIP forward and backward."""
+
+    @staticmethod
+    def forward(fctx, geom: _Geom, n_layers: int, x_tab: Tensor, *args: Tensor):
+        Tfs, params = args[:n_layers], args[n_layers:]
+        ctx, rb, z = geom.ctx, geom.rb, geom.z
+        x = ops.gather_rows(x_tab.detach().contiguous(), z)
+        saved = []
+        for i in range(n_layers):
+            Wnw, bnw, W3, Wb, Wn1, bn1, Wn2, bn2, Wout = [p.detach() for p in params[i * 9:(i + 1) * 9]]
+            V = W3.shape[0]
+            xs = ops.dense(x, Wnw[:V], bnw[:V])
+            xk = ops.dense(x, Wnw[V:], bnw[V:])
+            gate = torch.sigmoid(xk)
+            Ps = ops.dense(xs, Wn1[:, :V].contiguous(), bn1)
+            Pt = ops.dense(xs, Wn1[:, V:].contiguous())
+            Tf = Tfs[i].detach().contiguous()
+            Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, gate, geom.n_l, geom.zd)
+            tbw = ops.triplet_gemm(Ag, gram, geom.uvec_p, ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
+            ft = ops.dense(tbw, W3)
+            lw = ops.edge_combine(ft, B, None)
+            bw = ops.dense(lw, Wb)
+            pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
+            h1 = F.silu(pre1)
+            pre2 = ops.dense(h1, Wn2, bn2)
+            agg = ops.segment_sum(bw, ctx.out_ptr, F.silu(pre2))
+            x_new = ops.dense(agg, Wout, None, ops.ACT_NONE, x)
+            saved.append(dict(x=x, xs=xs, xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, tbw=tbw, ft=ft, bw=bw,
+                              pre1=pre1, pre2=pre2, agg=agg))
+            x = x_new
+        fctx.geom, fctx.n_layers, fctx.saved = geom, n_layers, saved
+        fctx.params = [p.detach() for p in params]
+        fctx.x_tab_shape = x_tab.shape
+        return x
+
+    @staticmethod
+    def backward(fctx, g_x: Tensor):
+        geom, L, saved, params = fctx.geom, fctx.n_layers, fctx.saved, fctx.params
+        ctx, rb, z = geom.ctx, geom.rb, geom.z
+        N, E = geom.N, ctx.n_edges
+        g_x = g_x.contiguous().float()
+        g_Tf = [None] * L
+        g_params = [None] * (9 * L)
+        g_rb_sink = torch.zeros_like(rb)   # dE/drb is produced by the kernel; positions are not differentiated here
+        m_in = (ctx.in_ptr[1:] - ctx.in_ptr[:-1]).long()
+        m_out = (ctx.out_ptr[1:] - ctx.out_ptr[:-1]).long()
+        prod = m_in * m_out
+        tbase = (torch.cumsum(prod, 0) - prod).contiguous()
+        n_dense = None   # only the any-V fallback of the three-body backward needs the scratch size (host sync)
+        for i in reversed(range(L)):
+            Wnw, bnw, W3, Wb, Wn1, bn1, Wn2, bn2, Wout = params[i * 9:(i + 1) * 9]
+            sv = saved[i]
+            V = W3.shape[0]
+            gp = g_params
+            # x' = x + agg Wout^T
+            gp[i * 9 + 8] = _mm_t(g_x, sv["agg"])
+            g_agg = ops.dense(g_x, Wout.t().contiguous())
+            g_bw, g_pre2 = ops.message_bwd(g_agg, ctx.src_p, sv["bw"], sv["pre2"])
+            h1 = F.silu(sv["pre1"])
+            gp[i * 9 + 6] = _mm_t(g_pre2, h1)
+            gp[i * 9 + 7] = g_pre2.sum(0)
+            g_h1 = ops.dense(g_pre2, Wn2.t().contiguous())
+            g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
+            g_Ps = ops.segment_sum(g_pre1, ctx.out_ptr)
+            g_Pt = ops.segment_sum(ops.gather_rows(g_pre1, ctx.in_pos), ctx.in_ptr)
+            lw = ops.edge_combine(sv["ft"], sv["B"], None)
+            gp[i * 9 + 3] = _mm_t(g_bw, lw)
+            g_lw = ops.dense(g_bw, Wb.t().contiguous())
+            g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
+            gp[i * 9 + 2] = _mm_t(g_ft, sv["tbw"])
+            g_tbw = ops.dense(g_ft, W3.t().contiguous())
+            if V not in ops.FUSED_WIDTHS and n_dense is None:
+                n_dense = int(prod.sum().item())
+            g_Ag, g_gram, _, _ = ops.triplet_bwd(g_tbw, sv["Ag"], sv["gram"], geom.uvec_p, ctx.src_p, ctx.dst_p, ctx.in_ptr,
+                                                 ctx.in_pos, ctx.out_ptr, tbase, n_dense or 1, E, N)
+            g_gate_part, g_A = ops.pair_contract_bwd(sv["Tf"], rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p,
+                                                     sv["gate"], g_Ag, g_B, g_gram, E, geom.n_l, geom.zd, g_rb_sink,
+                                                     want_gA=True)
+            partial = ops.pair_table_grad(g_A, rb, ctx.order, geom.l_of_d, geom.perm_pair, geom.chunk_ptr)
+            D = rb.shape[1]
+            g_Tf[i] = ops.segment_sum(partial.reshape(partial.shape[0], D * V), geom.pair_cptr).reshape(-1, D, V)
+            g_gate = ops.segment_sum(g_gate_part, ctx.out_ptr)
+            g_xk = ops.act_bwd(g_gate, sv["xk"], ops.ACT_SIGMOID)
+            xs = sv["xs"]
+            gp[i * 9 + 4] = torch.cat([_mm_t(g_Ps, xs), _mm_t(g_Pt, xs)], dim=1)
+            gp[i * 9 + 5] = g_Ps.sum(0)
+            g_xs = ops.dense(g_Ps, Wn1[:, :V].t().contiguous())
+            g_xs = ops.dense(g_Pt, Wn1[:, V:].t().contiguous(), None, ops.ACT_NONE, g_xs)
+            g_nw = torch.cat([g_xs, g_xk], dim=1)
+            gp[i * 9 + 0] = _mm_t(g_nw, sv["x"])
+            gp[i * 9 + 1] = g_nw.sum(0)
+            g_x = ops.dense(g_nw, Wnw.t().contiguous(), None, ops.ACT_NONE, g_x)
+        g_x_tab = ops.segment_sum(ops.gather_rows(g_x, geom.order_z.to(torch.int32)), geom.ptr_z)
+        return (None, None, g_x_tab.reshape(fctx.x_tab_shape), *g_Tf, *g_params)
+
+
+def forward_differentiable(model, graph):
+    """LCAONet.forward with an autograd graph to every parameter (training).  Same outputs as the inference path."""
+    if model.add_valence:
+        raise NotImplementedError("training with add_valence=True is not built yet")
+    if model.regress_forces and not model.direct_forces:
+        raise NotImplementedError("training on autograd forces needs a double backward, which is not built yet")
+    for layer in model.int_layers:
+        if not all(type(layer.f_node[k]) is nn.SiLU for k in (1, 3)):
+            raise NotImplementedError("the differentiable path is built for the default SiLU activation")
+    z = graph[GraphKeys.Z]
+    idx_s, idx_t = graph[GraphKeys.Edge_idx]
+    ops._dev(graph[GraphKeys.Pos], "graph.pos")
+    batch_idx = graph.get(GraphKeys.Batch_idx)
+    with torch.no_grad():
+        geom = _Geom(model, graph)
+    x_tab, cst_pair, pair, zd = species_tables_autograd(model, z, idx_s, idx_t)
+    with torch.no_grad():
+        geom.pair_lists(pair, zd)
+    L = model.n_interaction
+    Tfs = [_mlp(layer.f_coeffs, cst_pair) for layer in model.int_layers]
+    params = []
+    for layer in model.int_layers:
+        sd = dict(layer.named_parameters())
+        params += [sd[k] for k in PER_LAYER]
+    x = LCAOStackFn.apply(geom, L, x_tab, *Tfs, *params)
+    # heads: N-level MLPs and the per-graph reduction as torch ops under autograd
+    ol = model.out_layer
+    prop = _mlp(ol.out_lin, x)
+    if batch_idx is not None:
+        lat = graph.get(GraphKeys.Lattice)
+        B = lat.shape[0] if (lat is not None and lat.dim() == 3) else int(batch_idx.max().item()) + 1
+        out = torch.zeros(B, prop.shape[1], device=prop.device).index_add_(0, batch_idx, prop)
+        cnt = torch.zeros(B, device=prop.device).index_add_(0, batch_idx, torch.ones_like(batch_idx, dtype=prop.dtype))
+        if not ol.is_extensive:
+            out = out / cnt.clamp(min=1).unsqueeze(1)
+    else:
+        B = 1
+        out = prop.sum(0, keepdim=True) if ol.is_extensive else prop.mean(0, keepdim=True)
+        cnt = torch.full((1,), float(z.numel()), device=prop.device)
+    pp = model.pp_layer
+    if pp.atomref is not None:
+        aref = pp.atomref[z]
+        a = torch.zeros(B, aref.shape[1], device=prop.device).index_add_(0, batch_idx, aref) if batch_idx is not None \
+            else aref.sum(0, keepdim=True)
+        out = out + (a if pp.is_extensive else a / cnt.clamp(min=1).unsqueeze(1))
+    if pp.mean is not None:
+        out = out + (pp.mean.unsqueeze(0) * cnt.unsqueeze(1) if pp.is_extensive else pp.mean.unsqueeze(0))
+    if model.regress_forces:  # direct forces head (lcaonet.py:303-308)
+        f = _mlp(ol.out_lin_force, torch.cat([x[idx_s], x[idx_t]], dim=-1)) * geom.uvec
+        force = torch.zeros(z.numel(), 3, device=f.device).index_add_(0, idx_s, f)
+        return out, force
+    return out

@@ -388,15 +388,28 @@ def triplet_bwd(g_tbw, Ag, gram, uvec_p, src_p, dst_p, in_ptr, in_pos, out_ptr, 
     return g_Ag, g_gram, g_uq, g_up
 
 
-def pair_contract_bwd(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, e_own, n_l, zdim, g_rb):
+def pair_contract_bwd(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, e_own, n_l, zdim, g_rb,
+                      want_gA: bool = False):
     Tf, rb, gate, g_Ag, g_B, g_gram = _f32(Tf), _f32(rb), _f32(gate), _f32(g_Ag), _f32(g_B), _f32(g_gram)
     z = _i64(z)
     E, D = rb.shape
     V = Tf.shape[-1]
     g_gate_part = torch.empty(E, V, device=rb.device, dtype=torch.float32)
+    g_A = torch.empty(E, n_l, V, device=rb.device, dtype=torch.float32) if want_gA else None
     _call("lcao_pair_contract_bwd", _p(Tf), _p(rb), _p(order), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate), _p(g_Ag),
-          _p(g_B), _p(g_gram), E, e_own, D, V, n_l, zdim, _p(g_rb), _p(g_gate_part), _stream())
-    return g_gate_part
+          _p(g_B), _p(g_gram), E, e_own, D, V, n_l, zdim, _p(g_rb), _p(g_gate_part), _p(g_A), _stream())
+    return (g_gate_part, g_A) if want_gA else g_gate_part
+
+
+def pair_table_grad(g_A, rb, order, l_of_d, perm, chunk_ptr):
+    g_A, rb = _f32(g_A), _f32(rb)
+    E, n_l, V = g_A.shape
+    D = rb.shape[1]
+    n_chunks = chunk_ptr.numel() - 1
+    partial = torch.empty(n_chunks, D, V, device=rb.device, dtype=torch.float32)
+    _call("lcao_pair_table_grad", _p(g_A), _p(rb), _p(order), _p(l_of_d), _p(perm), _p(chunk_ptr), n_chunks, D, V, n_l,
+          _p(partial), _stream())
+    return partial
 
 
 def geometry_bwd(dist, uvec, g_rb, g_u, orb_table, rbf_kind, cutoff_kind, rc):
