@@ -599,7 +599,8 @@ extern "C" int lcao_geometry_bwd(const float* dist, const float* uvec, const flo
 // sorted list, chunks never span pairs); one wave per chunk writes a partial (D, V) table; the caller sums each pair's
 // partials in order (lcao_segment_sum) — deterministic, no atomics.
 // ---------------------------------------------------------------------------------------------------
-template <int R>
+// D accumulators per lane (DMAX orbitals at a time) so that every g_A row of the chunk is read once per pass
+template <int R, int DMAX>
 __global__ void k_pair_table_grad(const float* __restrict__ g_A, const float* __restrict__ rb,
                                   const int32_t* __restrict__ order, const int32_t* __restrict__ l_of_d,
                                   const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_ptr,
@@ -609,25 +610,45 @@ __global__ void k_pair_table_grad(const float* __restrict__ g_A, const float* __
   int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (; c < n_chunks; c += nwave) {
     const int i0 = chunk_ptr[c], i1 = chunk_ptr[c + 1];
-    for (int d = 0; d < D; ++d) {
-      const int l = l_of_d[d];
-      float acc[R];
+    for (int d0 = 0; d0 < D; d0 += DMAX) {
+      float acc[DMAX][R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = 0.f;
+      for (int dd = 0; dd < DMAX; ++dd)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[dd][r] = 0.f;
       for (int i = i0; i < i1; ++i) {
         const int p = perm[i];
         const int64_t e = order ? order[p] : p;
-        const float w = rb[e * D + d];
+        float ga[4][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int ch = lane + 64 * r;
-          if (ch < V) acc[r] += w * g_A[((int64_t)p * NL + l) * V + ch];
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int ch = lane + 64 * r;
+            ga[l][r] = (l < NL && ch < V) ? g_A[((int64_t)p * NL + l) * V + ch] : 0.f;
+          }
+#pragma unroll
+        for (int dd = 0; dd < DMAX; ++dd) {
+          const int d = d0 + dd;
+          if (d < D) {
+            const float w = rb[e * D + d];
+            const int l = l_of_d[d];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              acc[dd][r] += w * (l == 0 ? ga[0][r] : (l == 1 ? ga[1][r] : (l == 2 ? ga[2][r] : ga[3][r])));
+          }
         }
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int ch = lane + 64 * r;
-        if (ch < V) partial[(c * D + d) * V + ch] = acc[r];
+      for (int dd = 0; dd < DMAX; ++dd) {
+        const int d = d0 + dd;
+        if (d < D) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int ch = lane + 64 * r;
+            if (ch < V) partial[(c * D + d) * V + ch] = acc[dd][r];
+          }
+        }
       }
     }
   }
@@ -645,9 +666,9 @@ extern "C" int lcao_pair_table_grad(const float* g_A, const float* rb, const int
   dim3 grid(lcao_blocks(n_chunks, 4, 65536)), block(256);
   hipStream_t st = (hipStream_t)stream;
   int R = (V + 63) / 64;
-#define PTG(RR)                                                                                                      \
-  hipLaunchKernelGGL(k_pair_table_grad<RR>, grid, block, 0, st, g_A, rb, order, l_of_d, perm, chunk_ptr, n_chunks, n_orb, \
-                     V, n_l, partial)
+#define PTG(RR)                                                                                                        \
+  hipLaunchKernelGGL((k_pair_table_grad<RR, 8>), grid, block, 0, st, g_A, rb, order, l_of_d, perm, chunk_ptr, n_chunks,   \
+                     n_orb, V, n_l, partial)
   if (R == 1) PTG(1);
   else if (R == 2) PTG(2);
   else if (R <= 4) PTG(4);
