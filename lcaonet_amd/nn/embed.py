@@ -18,6 +18,8 @@ from .base import Dense, run_mlp
 
 
 class EmbedZ(nn.Module):
+    """Atomic number -> vector.  One row per element 1..max_z (the lookup index is z - 1)."""
+
     def __init__(self, emb_size: int, max_z: int = 94):
         super().__init__()
         self.emb_size = emb_size
@@ -25,37 +27,44 @@ class EmbedZ(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
-        self.z_embed.weight.data.uniform_(-math.sqrt(3), math.sqrt(3))
+        bound = math.sqrt(3.0)
+        with torch.no_grad():
+            self.z_embed.weight.uniform_(-bound, bound)
 
     def forward(self, z: Tensor) -> Tensor:
         return self.z_embed(z - 1)
 
 
 class EmbedElec(nn.Module):
-    """Per-orbital occupation embeddings; orbitals above `min_orb` get padding_idx=0 (a zero vector for an
-    empty orbital) unless extend_orb."""
+    """Ground-state occupation of every orbital -> vector, one lookup table per orbital.
+
+    An orbital the element does not occupy maps to the zero vector (padding_idx = 0) unless `extend_orb` is set or
+    the orbital lies at or below `min_orb` (embed.py:63-71)."""
 
     def __init__(self, emb_size: int, elec_info: ElecInfo, extend_orb: bool = False):
         super().__init__()
+        self.emb_size, self.extend_orb, self.n_orb = emb_size, extend_orb, elec_info.n_orb
         self.register_buffer("elec", elec_info.elec_table)
-        self.n_orb = elec_info.n_orb
-        self.emb_size = emb_size
-        self.extend_orb = extend_orb
-        self.e_embeds = nn.ModuleList()
-        min_idx = elec_info.min_orb_idx if elec_info.min_orb_idx else -1
-        for i, max_e in enumerate(elec_info.max_elec_idx):
-            padding_idx = None if (i <= min_idx or extend_orb) else 0
-            self.e_embeds.append(nn.Embedding(int(max_e), emb_size, padding_idx=padding_idx))
+        always_on = -1 if not elec_info.min_orb_idx else elec_info.min_orb_idx
+        tables = []
+        for orb, vocab in enumerate(elec_info.max_elec_idx.tolist()):
+            pad = None if (extend_orb or orb <= always_on) else 0
+            tables.append(nn.Embedding(vocab, emb_size, padding_idx=pad))
+        self.e_embeds = nn.ModuleList(tables)
         self.reset_parameters()
 
     def reset_parameters(self):
-        for ee in self.e_embeds:
-            ee.weight.data.uniform_(-math.sqrt(2), math.sqrt(2))
-            ee._fill_padding_idx_with_zero()
+        bound = math.sqrt(2.0)
+        with torch.no_grad():
+            for table in self.e_embeds:
+                table.weight.uniform_(-bound, bound)
+                if table.padding_idx is not None:
+                    table.weight[table.padding_idx].zero_()
 
     def forward(self, z: Tensor) -> Tensor:
-        elec = self.elec[z]  # (N, n_orb)
-        return torch.stack([ce(elec[:, i]) for i, ce in enumerate(self.e_embeds)], dim=1)  # (N, n_orb, emb)
+        occ = self.elec[z]                                          # (N, n_orb) electron counts
+        cols = [table(occ[:, orb]) for orb, table in enumerate(self.e_embeds)]
+        return torch.stack(cols, dim=1)                             # (N, n_orb, emb)
 
 
 class ValenceMask(nn.Module):

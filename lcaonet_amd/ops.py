@@ -171,6 +171,8 @@ def segment_sum(a: Tensor, ptr: Tensor, b: Tensor | None = None) -> Tensor:
     n_seg = ptr.numel() - 1
     width = a.shape[1] if a.dim() > 1 else 1
     b = _f32(b, "b") if b is not None else None
+    if a.shape[0] == 0:   # no rows at all (edgeless graph): every segment is empty
+        return torch.zeros((n_seg, width), device=a.device, dtype=torch.float32)
     out = torch.empty((n_seg, width), device=a.device, dtype=torch.float32)
     _call("lcao_segment_sum", _p(a), _p(b), _p(ptr), n_seg, width, _p(out), _stream())
     return out

@@ -621,3 +621,36 @@ def test_training_reduces_loss(dev, golden_loader):
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
+
+
+def test_high_degree_nodes_and_empty_graph(dev):
+    """Dense clusters: 90 atoms all within the cutoff, so every node has 89 in-edges and 89 out-edges (more than one
+    64-id chunk and six 16-edge tiles per node) — forward, autograd forces and parameter gradients against the oracle.
+    And a graph without any edge."""
+    from lcaonet_amd.data.graph import Data
+    from lcaonet_amd.data.synthetic import random_molecules
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=9.0, max_z=10)
+    g = random_molecules(2, 90, 4.0, 0.99 * 9.0, seed=3)
+    deg = torch.bincount(g["edge_index"][0])
+    assert int(deg.min()) == 89 and int(deg.max()) == 89
+    m, sd = _random_model(dev, 91, **kw)
+    want, _ = _oracle_run(sd, kw, g.to_dict())
+    for mode in ("edge", "pair"):
+        assert relerr(m(g.to(dev), cst_mode=mode), want) <= TOL
+    kwf = dict(kw, regress_forces=True, direct_forces=False)
+    mf, sdf = _random_model(dev, 92, **kwf)
+    wout, wforce = O.forward(sdf, _ocfg({**kwf, "rbf_type": "hydrogen"}), g.to_dict(), dtype=torch.float64)
+    out, force = mf(g.to(dev))
+    assert relerr(out, wout.detach()) <= TOL and relerr(force, wforce.detach()) <= 5 * TOL
+    # no edges at all: outputs come from the node embedding alone.  The reference (and the oracle) cannot run E = 0
+    # (reshape(E, -1) in embed.py:249), so the expected value is the oracle on the same atoms plus ONE edge beyond the
+    # cutoff, whose radial basis — hence its message — is exactly zero.
+    pos = torch.tensor([[0.0, 0.0, 0.0], [20.0, 0.0, 0.0], [0.0, 20.0, 0.0]])
+    ge = Data(z=torch.tensor([1, 6, 8], device=dev), pos=pos.to(dev),
+              edge_index=torch.zeros(2, 0, dtype=torch.long, device=dev), edge_shift=torch.zeros(0, 3, device=dev),
+              lattice=torch.eye(3, device=dev).unsqueeze(0) * 50)
+    oe = m(ge)
+    g1 = dict(z=torch.tensor([1, 6, 8]), pos=pos, edge_index=torch.tensor([[0], [1]]), edge_shift=torch.zeros(1, 3),
+              lattice=torch.eye(3).unsqueeze(0) * 50)
+    we, _ = _oracle_run(sd, kw, g1)
+    assert relerr(oe, we) <= TOL
