@@ -173,6 +173,16 @@ def main():
             pair_ms = 1e3 * (time.perf_counter() - t1) / args.steps
     except NotImplementedError:
         pass
+    # secondary measurement: BASELINE config 3 (bf16 MFMA on the per-edge coefficient GEMMs, two-term split)
+    with torch.no_grad():
+        out_bf = model(batch, precision="bf16x3")
+        bf_err = float((out_bf - out).abs().max() / out.abs().max())
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            model(batch, precision="bf16x3")
+        torch.cuda.synchronize()
+        bf_ms = 1e3 * (time.perf_counter() - t2) / args.steps
 
     t = torch.tensor([elapsed, float(E)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -232,6 +242,11 @@ def main():
                 "note": "NOT the headline: LCAONet.forward(cst_mode='pair') — f_coeffs evaluated on the (z_s,z_t) species-pair "
                         "table (SURVEY.md 8f-2) instead of per edge; same outputs", "ms_per_step_rank0": round(pair_ms, 3),
                 "edges_per_s_rank0": E / (pair_ms * 1e-3), "max_rel_diff_vs_headline_output": pair_err}
+        line["bf16x3_mode"] = {
+            "note": "NOT the headline: BASELINE config 3 — per-edge coefficient GEMMs on bf16 MFMA, each fp32 operand split "
+                    "into two bf16 terms (3 MFMAs per product, fp32 accumulate); general per-edge cst", "dtype": "bf16x3",
+            "ms_per_step_rank0": round(bf_ms, 3), "edges_per_s_rank0": E / (bf_ms * 1e-3),
+            "max_rel_diff_vs_fp32_output": bf_err}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -162,6 +162,14 @@ int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* or
                             void* workspace /* device, >= 8 bytes: tile-queue counters, zeroed by the call */,
                             size_t ws_bytes, void* stream);
 
+/* BASELINE config 3: the same fused kernel with both Dense layers on bf16 MFMA, every fp32 operand split into two
+ * bf16 terms and each product run as three MFMAs with fp32 accumulation ("bf16x3": 6-9e-6 relative error on the MLP,
+ * against 3.6e-3 for plain bf16).  No valence.  workspace >= 4 bytes. */
+int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                                   const float* W1, const float* W2, const float* gate, const int32_t* src_p,
+                                   int64_t n_edges, int n_orb, int C, int V, int n_l, float* A, float* B, float* Ag,
+                                   float* gram, void* workspace, size_t ws_bytes, void* stream);
+
 /* lcaonet.py:173-189 as one small fp32-MFMA GEMM per centre node (no LDS, no T-sized tensor):
  *   tbw[p,:] = sum_{q in In(s), q != p}  sum_l  Y_l(u_p.u_q) / max(sqrt(Y^T G_q Y), 1e-12) * Ag[q,l,:]
  * Ag / gram from lcao_coeff_mlp_contract; uvec_p (E,3) unit vectors in p-space; CSR as lcao_triplet_sum. */

@@ -216,7 +216,7 @@ class LCAOInteraction(nn.Module):
     def forward_fused(self, x: Tensor, cst: Tensor, valence_ed: Tensor | None, rb: Tensor, uvec: Tensor,
                       ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
                       trace: dict | None = None, exact_norm: bool = False, n_own: int | None = None,
-                      e_own: int | None = None, pair: tuple | None = None) -> Tensor:
+                      e_own: int | None = None, pair: tuple | None = None, precision: str = "fp32") -> Tensor:
         """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1.
 
         n_own / e_own (sharded graphs, lcaonet_amd/shard.py): only the first n_own nodes are centres to update and
@@ -245,6 +245,15 @@ class LCAOInteraction(nn.Module):
             Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
             Bv = None
             tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
+        elif fused and precision == "bf16x3" and not self.add_valence:
+            # BASELINE config 3: bf16 MFMA on the per-edge coefficient GEMMs, operands split into two bf16 terms
+            Ag, gram, B, Bv = ops.coeff_mlp_contract_bf16x3(
+                cst, rb, ctx.order, l_of_d, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(), n_l,
+                gate=None if exact_norm else gate, src_p=ctx.src_p)
+            if exact_norm:
+                tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
+            else:
+                tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
         elif fused:
             Ag, gram, B, Bv = ops.coeff_mlp_contract(
                 cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
@@ -467,9 +476,12 @@ class LCAONet(BaseMPNN):
     # --- forward ------------------------------------------------------------------------------------------
     def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
                 trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
-                differentiable: bool | None = None):
+                differentiable: bool | None = None, precision: str = "fp32"):
         """graph: PyG-Batch-like object with z, pos, edge_index [centre, neighbour], edge_shift, lattice and
         optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
+
+        precision: "fp32" (default; exact fp32 MFMA) or "bf16x3" (BASELINE config 3: the per-edge coefficient GEMMs on
+        bf16 MFMA with two-term operand splitting; ~1e-5 from fp32 where plain bf16 would be 4e-3).
 
         differentiable (default: `self.training and torch.is_grad_enabled()`): record an autograd graph to every
         parameter (model/train.py: HIP forward + hand-written HIP backward of the interaction stack).  Otherwise the
@@ -480,11 +492,14 @@ class LCAONet(BaseMPNN):
             from .train import forward_differentiable
 
             return forward_differentiable(self, graph)
-        return self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode)
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"precision={precision!r}: expected 'fp32' or 'bf16x3'")
+        return self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision)
 
     @torch.no_grad()
     def _forward_inference(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
-                           trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge"):
+                           trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
+                           precision: str = "fp32"):
         if self.regress_forces and not self.direct_forces:
             # F = -dE/dpos (lcaonet.py:310-317): species-pair forward + hand-written reverse sweep (model/forces.py)
             from .forces import forward_with_autograd_forces
@@ -526,7 +541,7 @@ class LCAONet(BaseMPNN):
         for i, inte in enumerate(self.int_layers):
             tr = {} if trace is not None else None
             x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr, exact_norm,
-                                   pair=pair)
+                                   pair=pair, precision=precision)
             if trace is not None:
                 trace[f"x{i + 1}"] = x
                 trace[f"three_body_w{i + 1}"] = tr["three_body_w"]

@@ -214,6 +214,25 @@ def coeff_contract(cstf, rb, order, l_of_d, mask, V, n_l, valence):
     return A, B, Bv
 
 
+def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, src_p=None):
+    """bf16-MFMA ("bf16x3" split) variant of coeff_mlp_contract; same outputs (no valence)."""
+    cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
+    E, D = rb.shape
+    V, C = W1.shape
+    dev = rb.device
+    B = torch.empty(E, V, device=dev, dtype=torch.float32)
+    gated = gate is not None
+    A = None if gated else torch.empty(E, n_l, V, device=dev, dtype=torch.float32)
+    Ag = torch.empty(E, n_l, V, device=dev, dtype=torch.float32) if gated else None
+    gram = torch.empty(E, 10, device=dev, dtype=torch.float32) if gated else None
+    if gated:
+        gate = _f32(gate, "gate")
+    ws = torch.empty(2, device=dev, dtype=torch.int32)
+    _call("lcao_coeff_mlp_contract_bf16x3", _p(cst), _p(rb), _p(order), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
+          D, C, V, n_l, _p(A), _p(B), _p(Ag), _p(gram), _p(ws), 8, _stream())
+    return (Ag if gated else A), gram, B, None
+
+
 def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence, gate=None, src_p=None):
     """Fused f_coeffs + radial contraction.  With `gate` (N,V) and `src_p`: returns (Ag, gram, B, Bv) for
     triplet_gemm; without: (A, None, B, Bv) for the exact-norm triplet_sum."""
