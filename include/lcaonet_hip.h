@@ -177,6 +177,13 @@ int lcao_triplet_gemm(const float* Ag, const float* gram, const float* uvec_p, c
                       const int32_t* in_pos, const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int V, int n_l,
                       float* tbw, void* stream);
 
+/* bf16x3 forms of the two fused two-body kernels below (same arguments, same split as lcao_coeff_mlp_contract_bf16x3) */
+int lcao_edge_lcao_weight_bf16x3(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges,
+                                 int V, float* bw, void* stream);
+int lcao_edge_node_message_bf16x3(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                  const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
+                                  float* msg, void* stream);
+
 /* Species-pair form of lcaonet.py:170-183,200 (eval mode, no valence): with
  * Tf[(z_s*zdim + z_t), d, :] = f_coeffs(cst(z_s, z_t))[d, :] precomputed on the (zdim^2, D, V) pair table,
  *   A[p,l,:] = sum_{d in l} rb[e,d] * Tf[pair(p),d,:];  writes Ag = A * gate[src_p], B = sum_l A, gram = A A^T

@@ -42,6 +42,8 @@ SIGNATURES = {
     "lcao_pair_contract": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],
     "lcao_edge_lcao_weight": [P, P, P, P, L, I, P, P],
     "lcao_edge_node_message": [P, P, P, P, P, P, P, L, I, P, P],
+    "lcao_edge_lcao_weight_bf16x3": [P, P, P, P, L, I, P, P],
+    "lcao_edge_node_message_bf16x3": [P, P, P, P, P, P, P, L, I, P, P],
     "lcao_act_bwd": [P, P, L, I, P, P],
     "lcao_pair_pre": [P, P, P, P, L, I, P, P],
     "lcao_message_bwd": [P, P, P, P, L, I, P, P, P],

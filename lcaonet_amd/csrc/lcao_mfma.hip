@@ -1390,3 +1390,183 @@ extern "C" int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb,
 #undef BF_CASE
   return LCAO_ERR_UNSUPPORTED;
 }
+
+// ===================================================================================================
+// bf16x3 forms of the two-body kernels (same split as k_coeff_mlp_bf16x3; `precision="bf16x3"`).
+// bf_layer: one Dense layer on a 16-row tile, input given as 8 floats per 32-wide k-step in B-operand order.
+// ===================================================================================================
+template <int KS, int MT>
+__device__ __forceinline__ void bf_layer(const __bf16* __restrict__ wh, const __bf16* __restrict__ wl, int ld, int r,
+                                         int q, const float (&in)[KS][8], f32x4v (&out)[MT]) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    bf16x8v xh, xl;
+    split8(in[s], xh, xl);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bf16x8v a_h = *(const bf16x8v*)(wh + (16 * m + r) * ld + 32 * s + 8 * q);
+      const bf16x8v a_l = *(const bf16x8v*)(wl + (16 * m + r) * ld + 32 * s + 8 * q);
+      out[m] = MFMA16BF(a_h, xl, out[m]);
+      out[m] = MFMA16BF(a_l, xh, out[m]);
+      out[m] = MFMA16BF(a_h, xh, out[m]);
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_edge_lcao_weight_bf(const float* __restrict__ tbw, const float* __restrict__ B,
+                                                             const float* __restrict__ W3, const float* __restrict__ Wb,
+                                                             int64_t E, float* __restrict__ bw) {
+  constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
+  extern __shared__ __bf16 ldsb[];
+  __bf16* w3h = ldsb;
+  __bf16* w3l = w3h + V * LD;
+  __bf16* wbh = w3l + V * LD;
+  __bf16* wbl = wbh + V * LD;
+  stage_weights_bf16x2<false>(w3h, w3l, W3, V, V);
+  stage_weights_bf16x2<true>(wbh, wbl, Wb, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (E + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t p = tile * 16 + r;
+    const bool valid = p < E;
+    const int64_t pc = valid ? p : E - 1;
+    float xin[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f32x4v a = *(const f32x4v*)(tbw + pc * V + 32 * s + 8 * q);
+      const f32x4v b = *(const f32x4v*)(tbw + pc * V + 32 * s + 8 * q + 4);
+      xin[s][0] = a[0]; xin[s][1] = a[1]; xin[s][2] = a[2]; xin[s][3] = a[3];
+      xin[s][4] = b[0]; xin[s][5] = b[1]; xin[s][6] = b[2]; xin[s][7] = b[3];
+    }
+    f32x4v bb[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bb[m] = *(const f32x4v*)(B + pc * V + 16 * m + 4 * q);
+    f32x4v ft[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ft[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    bf_layer<KS, MT>(w3h, w3l, LD, r, q, xin, ft);
+    float n2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = bb[m][j] + bb[m][j] * ft[m][j];
+        ft[m][j] = u;
+        n2 += u * u;
+      }
+    n2 += __shfl_xor(n2, 16);
+    n2 += __shfl_xor(n2, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    float lin[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lin[s][j] = ft[2 * s][j] * inv;
+        lin[s][4 + j] = ft[2 * s + 1][j] * inv;
+      }
+    f32x4v o[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    bf_layer<KS, MT>(wbh, wbl, LD, r, q, lin, o);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *(f32x4v*)(bw + p * V + 16 * m + 4 * q) = o[m];
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_edge_node_message_bf(
+    const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
+    const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, const float* __restrict__ Wn2,
+    const float* __restrict__ bn2, int64_t E, float* __restrict__ msg) {
+  constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
+  extern __shared__ __bf16 ldsb[];
+  __bf16* wh = ldsb;
+  __bf16* wl = wh + V * LD;
+  stage_weights_bf16x2<false>(wh, wl, Wn2, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (E + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t p = tile * 16 + r;
+    const bool valid = p < E;
+    const int64_t pc = valid ? p : E - 1;
+    const float* ps = Ps + (int64_t)src_p[pc] * V + 8 * q;
+    const float* pt = Pt + (int64_t)dst_p[pc] * V + 8 * q;
+    float hin[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f32x4v a = *(const f32x4v*)(ps + 32 * s) + *(const f32x4v*)(pt + 32 * s);
+      const f32x4v b = *(const f32x4v*)(ps + 32 * s + 4) + *(const f32x4v*)(pt + 32 * s + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { hin[s][j] = lcao_silu(a[j]); hin[s][4 + j] = lcao_silu(b[j]); }
+    }
+    f32x4v o[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
+    bf_layer<KS, MT>(wh, wl, LD, r, q, hin, o);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        f32x4v w = *(const f32x4v*)(bw + p * V + 16 * m + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] *= lcao_silu(o[m][j]);
+        *(f32x4v*)(msg + p * V + 16 * m + 4 * q) = w;
+      }
+    }
+  }
+}
+
+extern "C" int lcao_edge_lcao_weight_bf16x3(const float* tbw, const float* B, const float* W3, const float* Wb,
+                                            int64_t n_edges, int V, float* bw, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(tbw); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(W3); LCAO_CHECK_PTR(Wb); LCAO_CHECK_PTR(bw);
+  hipStream_t st = (hipStream_t)stream;
+  size_t lds = size_t(4) * V * (V + 8) * sizeof(__bf16);
+#define LWB_CASE(V_)                                                                                            \
+  if (V == V_) {                                                                                                \
+    static bool done = false;                                                                                   \
+    int rc = set_lds_attr(k_edge_lcao_weight_bf<V_>, lds, done);                                                \
+    if (rc != LCAO_OK) return rc;                                                                               \
+    hipLaunchKernelGGL(k_edge_lcao_weight_bf<V_>, dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, tbw, B, \
+                       W3, Wb, n_edges, bw);                                                                    \
+    return lcao_launch_status();                                                                                \
+  }
+  LWB_CASE(128) LWB_CASE(64) LWB_CASE(32)
+#undef LWB_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}
+
+extern "C" int lcao_edge_node_message_bf16x3(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                             const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges,
+                                             int V, float* msg, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p);
+  LCAO_CHECK_PTR(Wn2); LCAO_CHECK_PTR(bn2); LCAO_CHECK_PTR(msg);
+  hipStream_t st = (hipStream_t)stream;
+  size_t lds = size_t(2) * V * (V + 8) * sizeof(__bf16);
+#define NMB_CASE(V_)                                                                                              \
+  if (V == V_) {                                                                                                  \
+    static bool done = false;                                                                                     \
+    int rc = set_lds_attr(k_edge_node_message_bf<V_>, lds, done);                                                 \
+    if (rc != LCAO_OK) return rc;                                                                                 \
+    hipLaunchKernelGGL(k_edge_node_message_bf<V_>, dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, bw, Ps, \
+                       Pt, src_p, dst_p, Wn2, bn2, n_edges, msg);                                                 \
+    return lcao_launch_status();                                                                                  \
+  }
+  NMB_CASE(128) NMB_CASE(64) NMB_CASE(32)
+#undef NMB_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}

@@ -273,9 +273,9 @@ class LCAOInteraction(nn.Module):
         Bv = Bv[:e_own] if Bv is not None else None
         # two-body term and messages
         if fused and not self.add_valence:
-            bw = ops.edge_lcao_weight(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach())
+            bw = ops.edge_lcao_weight(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach(), precision)
             msg = ops.edge_node_message(bw, Ps, Pt, src_own, dst_own, self.f_node[2].weight.detach(),
-                                        self.f_node[2].bias.detach())
+                                        self.f_node[2].bias.detach(), precision)
             agg = ops.segment_sum(msg, out_ptr)
         else:
             ft = run_mlp(self.f_three, tbw)

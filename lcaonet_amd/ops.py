@@ -334,19 +334,19 @@ def triplet_literal(cstf, rb, shb, xk, tri_k, e_ks, mask, V, valence):
     return w
 
 
-def edge_lcao_weight(tbw, B, W3, Wb):
+def edge_lcao_weight(tbw, B, W3, Wb, precision="fp32"):
     tbw, B, W3, Wb = _f32(tbw), _f32(B), _f32(W3), _f32(Wb)
     E, V = B.shape
     bw = torch.empty(E, V, device=B.device, dtype=torch.float32)
-    _call("lcao_edge_lcao_weight", _p(tbw), _p(B), _p(W3), _p(Wb), E, V, _p(bw), _stream())
+    _call("lcao_edge_lcao_weight_bf16x3" if precision == "bf16x3" else "lcao_edge_lcao_weight", _p(tbw), _p(B), _p(W3), _p(Wb), E, V, _p(bw), _stream())
     return bw
 
 
-def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2):
+def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, precision="fp32"):
     bw, Ps, Pt, Wn2, bn2 = _f32(bw), _f32(Ps), _f32(Pt), _f32(Wn2), _f32(bn2)
     E, V = bw.shape
     msg = torch.empty(E, V, device=bw.device, dtype=torch.float32)
-    _call("lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg),
+    _call("lcao_edge_node_message_bf16x3" if precision == "bf16x3" else "lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg),
                                           _stream())
     return msg
 

@@ -674,3 +674,5 @@ def test_cfg3_bf16x3_vs_oracle(dev, width):
     print(f"bf16x3 V={width}: three_body_w1 {e_tbw:.2e}  x3 {e_x:.2e}  out {e_out:.2e}")
     assert max(e_tbw, e_x, e_out) <= 1e-3          # the config's stated tolerance
     assert max(e_tbw, e_x, e_out) <= 1e-4          # what the two-term split actually delivers (regression guard)
+    e_pair = relerr(m(g.to(dev), precision="bf16x3", cst_mode="pair"), want)   # two-body kernels in bf16x3, pair table
+    assert e_pair <= 1e-4

@@ -9,15 +9,16 @@ dev = torch.device("cuda:0")
 gen_kw, model_kw = WORKLOADS["cfg2"]
 model = build_model(model_kw, 1234, dev)
 batch = jittered_cubic_cells(seed=1234, device=dev, **gen_kw)
-for mode in ("edge", "pair"):
+for mode in ("edge", "bf16x3", "pair"):
+    kw = dict(precision="bf16x3") if mode == "bf16x3" else dict(cst_mode=mode)
     with torch.no_grad():
         for _ in range(3):
-            model(batch, cst_mode=mode)
+            model(batch, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with ops.profile() as prof:
             for _ in range(10):
-                model(batch, cst_mode=mode)
+                model(batch, **kw)
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) / 10 * 1e3
             ks = prof.summary()
