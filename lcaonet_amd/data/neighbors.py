@@ -14,6 +14,7 @@ from torch import Tensor
 
 from .. import _lib, ops
 from .graph import Batch
+from .keys import GraphKeys
 
 
 def _graph_table(lattice: Tensor, pbc: Tensor, cutoff: float) -> tuple[Tensor, int]:
@@ -37,6 +38,28 @@ def _graph_table(lattice: Tensor, pbc: Tensor, cutoff: float) -> tuple[Tensor, i
     rec_i[:, 24:27] = pbc.int()
     rec_i[:, 27] = base.int()
     return rec_f, int(nbins.sum().item())
+
+
+def _link_isolated_graphs(pos: Tensor, b: Tensor, n_graphs: int, e_src, e_dst, e_shift, e_dist):
+    """Fully-linked fallback of data/utils.py:10-20 for every graph of the batch that has atoms but no edge
+    (pairs ordered by (centre, neighbour) as the reference's meshgrid gives them); plain torch, any device."""
+    n_atoms = torch.bincount(b, minlength=n_graphs)
+    n_edges = torch.bincount(b[e_src], minlength=n_graphs)
+    lonely = (n_edges == 0) & (n_atoms > 1)
+    if not bool(lonely.any()):
+        return e_src, e_dst, e_shift, e_dist
+    nodes = lonely[b].nonzero(as_tuple=True)[0]                  # atoms of the graphs to link, ascending
+    bb = b[nodes]
+    same = bb.unsqueeze(0) == bb.unsqueeze(1)
+    same.fill_diagonal_(False)
+    i, j = same.nonzero(as_tuple=True)                           # row-major: (centre, neighbour) ascending
+    a_src, a_dst = nodes[i], nodes[j]
+    a_dist = (pos[a_dst] - pos[a_src]).norm(dim=1)
+    src = torch.cat([e_src, a_src])
+    o = torch.argsort(src, stable=True)                          # keeps edges grouped by centre
+    return (src[o], torch.cat([e_dst, a_dst])[o],
+            torch.cat([e_shift, torch.zeros(a_src.numel(), 3, device=pos.device, dtype=e_shift.dtype)])[o],
+            torch.cat([e_dist, a_dist])[o])
 
 
 @torch.no_grad()
@@ -83,14 +106,9 @@ def neighbor_list(pos: Tensor, lattice: Tensor, cutoff: float, batch: Tensor | N
         rank = torch.arange(E, device=dev) - offset[e_src]
         keep = rank < max_neighbors
         e_src, e_dst, e_shift, e_dist = e_src[keep], e_dst[keep], e_shift[keep], e_dist[keep]
-    if e_src.numel() == 0 and N > 1:
-        # data/convert.py:154-157: no neighbour anywhere -> fully linked graph (within each graph), zero shifts
-        b = batch if batch is not None else torch.zeros(N, dtype=torch.long, device=dev)
-        same = b.unsqueeze(0) == b.unsqueeze(1)
-        same.fill_diagonal_(False)
-        e_src, e_dst = same.nonzero(as_tuple=True)
-        e_shift = torch.zeros(e_src.numel(), 3, device=dev)
-        e_dist = (pos[e_dst] - pos[e_src]).norm(dim=1)
+    # data/convert.py:154-157 (per structure): a graph in which no atom has a neighbour becomes fully linked, zero shifts
+    b = batch if batch is not None else torch.zeros(N, dtype=torch.long, device=dev)
+    e_src, e_dst, e_shift, e_dist = _link_isolated_graphs(pos, b, B, e_src, e_dst, e_shift, e_dist)
     return torch.stack([e_src, e_dst]), e_shift, e_dist
 
 
@@ -102,5 +120,10 @@ def make_graph(z: Tensor, pos: Tensor, lattice: Tensor, cutoff: float, batch: Te
     lattice = lattice.float().reshape(-1, 3, 3)
     if batch is None:
         batch = torch.zeros(z.numel(), dtype=torch.long, device=pos.device)
-    return Batch(z=z, pos=pos.float().contiguous(), edge_index=ei.contiguous(), edge_shift=shift.contiguous(),
-                 lattice=lattice.contiguous(), batch=batch)
+    B = lattice.shape[0]
+    pbc = torch.ones(B, 3, dtype=torch.long, device=pos.device) if pbc is None else pbc.to(pos.device).long().reshape(B, 3)
+    g = Batch(z=z, pos=pos.float().contiguous(), edge_index=ei.contiguous(), edge_shift=shift.contiguous(),
+              lattice=lattice.contiguous(), batch=batch)
+    g[GraphKeys.PBC] = pbc                                                    # convert.py:168-169
+    g[GraphKeys.Neighbors] = torch.bincount(batch[ei[0]], minlength=B)
+    return g

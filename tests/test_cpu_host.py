@@ -143,3 +143,19 @@ def test_synthetic_generators():
     assert int(torch.bincount(g2["edge_index"][0]).max()) <= 8
     g3 = random_molecules(4, 9, 4.0, 6.0)
     assert float(g3["edge_shift"].abs().max()) == 0.0
+
+
+def test_fully_linked_fallback_per_graph():
+    """data/convert.py:154-157 + data/utils.py:10-20: a structure without any neighbour becomes fully linked; the
+    helper applies it per graph of a batch and keeps edges grouped by centre."""
+    from lcaonet_amd.data.neighbors import _link_isolated_graphs
+    pos = torch.arange(21, dtype=torch.float32).view(7, 3)
+    b = torch.tensor([0, 0, 1, 1, 1, 2, 3])                       # graph 1: 3 atoms, no edges; graph 2/3: single atoms
+    e_src, e_dst = torch.tensor([0, 1]), torch.tensor([1, 0])
+    out = _link_isolated_graphs(pos, b, 4, e_src, e_dst, torch.ones(2, 3), torch.tensor([5.0, 5.0]))
+    s, t, sh, d = out
+    assert list(zip(s.tolist(), t.tolist())) == [(0, 1), (1, 0), (2, 3), (2, 4), (3, 2), (3, 4), (4, 2), (4, 3)]
+    assert sh[:2].eq(1).all() and sh[2:].eq(0).all()
+    assert torch.allclose(d[2:], (pos[t[2:]] - pos[s[2:]]).norm(dim=1))
+    same = _link_isolated_graphs(pos[:2], b[:2], 1, e_src, e_dst, torch.ones(2, 3), torch.tensor([5.0, 5.0]))
+    assert same[0] is e_src

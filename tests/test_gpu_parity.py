@@ -478,6 +478,20 @@ def test_neighbor_list_batched_and_model_roundtrip(dev):
     far = make_graph(host["z"][:4], torch.eye(3, device=dev)[[0, 1, 2, 0]] * torch.tensor([[10.], [20.], [30.], [40.]], device=dev),
                      torch.eye(3, device=dev).unsqueeze(0) * 200.0, 2.0)
     assert far["edge_index"].shape[1] == 12 and float(far["edge_shift"].abs().max()) == 0.0
+    # the fallback is per structure (convert.py:154-157): graph 1 of 3 has no pair inside the cutoff
+    pos = torch.cat([host["pos"][:14], torch.arange(3, device=dev).float().view(3, 1) * torch.tensor([[9.0, 7.0, 0.0]], device=dev),
+                     host["pos"][14:28]])
+    z = torch.cat([host["z"][:14], host["z"][:3], host["z"][14:28]])
+    b = torch.tensor([0] * 14 + [1] * 3 + [2] * 14, device=dev)
+    lat = torch.stack([host["lattice"][0], torch.eye(3, device=dev) * 60.0, host["lattice"][1]])
+    pbc = torch.tensor([[1, 1, 1], [0, 0, 0], [1, 1, 1]], dtype=torch.bool)
+    mixed = make_graph(z, pos, lat, 0.99 * 4.0, batch=b, pbc=pbc, max_neighbors=None)
+    s_, t_ = mixed["edge_index"]
+    mid = (b[s_] == 1)
+    assert int(mid.sum()) == 6 and sorted(zip(s_[mid].tolist(), t_[mid].tolist())) == [
+        (14, 15), (14, 16), (15, 14), (15, 16), (16, 14), (16, 15)]
+    assert bool((s_[1:] >= s_[:-1]).all()) and bool((b[s_] == b[t_]).all())
+    assert mixed["neighbors"].tolist() == [int((b[s_] == k).sum()) for k in range(3)] and mixed["pbc"].shape == (3, 3)
 
 
 def test_single_crystal_sharded_in_slabs(dev):
