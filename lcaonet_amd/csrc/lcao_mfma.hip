@@ -531,11 +531,13 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
 //   ft = W3 . tbw^T ;  u = B * (1 + ft) ;  lw = u / max(|u|, 1e-12) ;  bw = Wb . lw^T
 // The row norm is an in-lane sum over the lane's 4*MT features plus two cross-quarter shuffles.
 // ===================================================================================================
-template <int V>
-__global__ __launch_bounds__(256) void k_edge_lcao_weight(const float* __restrict__ tbw, const float* __restrict__ B,
-                                                          const float* __restrict__ W3, const float* __restrict__ Wb,
-                                                          int64_t E, float* __restrict__ bw) {
-  constexpr int MT = V / 16;
+template <int V, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_edge_lcao_weight(const float* __restrict__ tbw,
+                                                              const float* __restrict__ B,
+                                                              const float* __restrict__ W3,
+                                                              const float* __restrict__ Wb, int64_t E,
+                                                              float* __restrict__ bw) {
+  constexpr int MT = V / 16, WAVES = THREADS / 64;
   extern __shared__ float lds[];
   float* w3s = lds;
   float* wbs = lds + V * (V + 4);
@@ -545,20 +547,32 @@ __global__ __launch_bounds__(256) void k_edge_lcao_weight(const float* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t n_tiles = (E + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-    asm volatile("" ::: "memory");  // keep the LDS weight fragments from being hoisted out of the tile loop
-    const int64_t p = tile * 16 + r;
-    const bool valid = p < E;
-    const int64_t pc = valid ? p : E - 1;
-    f32x4v x[MT], b[MT];
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+  // the inputs of the next tile are fetched into the registers of the operand that has just been consumed
+  // (x after the first GEMM, b after the combine), so loads are in flight under the second GEMM and the store
+  f32x4v x[MT], b[MT];
+  if (tile < n_tiles) {
+    const int64_t pc = min(tile * 16 + r, E - 1);
 #pragma unroll
     for (int a = 0; a < MT; ++a) x[a] = *(const f32x4v*)(tbw + pc * V + 16 * a + 4 * q);
 #pragma unroll
     for (int a = 0; a < MT; ++a) b[a] = *(const f32x4v*)(B + pc * V + 16 * a + 4 * q);
+  }
+  for (; tile < n_tiles; tile += stride) {
+    asm volatile("" ::: "memory");  // keep the LDS weight fragments from being hoisted out of the tile loop
+    const int64_t p = tile * 16 + r;
+    const bool valid = p < E;
+    const int64_t nxt = tile + stride;
+    const int64_t pn = min(nxt * 16 + r, E - 1);
     f32x4v ft[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) ft[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
     mfma_layer<MT, MT>(w3s, V + 4, r, q, x, ft);
+    if (nxt < n_tiles) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) x[a] = *(const f32x4v*)(tbw + pn * V + 16 * a + 4 * q);
+    }
     float n2 = 0.f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -568,6 +582,10 @@ __global__ __launch_bounds__(256) void k_edge_lcao_weight(const float* __restric
         ft[m][j] = u;
         n2 += u * u;
       }
+    if (nxt < n_tiles) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) b[a] = *(const f32x4v*)(B + pn * V + 16 * a + 4 * q);
+    }
     n2 += __shfl_xor(n2, 16);
     n2 += __shfl_xor(n2, 32);
     const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
@@ -604,19 +622,42 @@ __global__ __launch_bounds__(256) void k_edge_node_message(const float* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t n_tiles = (E + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-    asm volatile("" ::: "memory");
-    const int64_t p = tile * 16 + r;
-    const bool valid = p < E;
-    const int64_t pc = valid ? p : E - 1;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  // software pipeline: the node rows of tile t+1 are gathered while tile t is on the matrix cores; their indices
+  // were read one iteration earlier
+  f32x4v h[MT];
+  int32_t sn = 0, dn = 0;
+  if (tile < n_tiles) {
+    const int64_t pc = min(tile * 16 + r, E - 1);
     const float* ps = Ps + (int64_t)src_p[pc] * V + 4 * q;
     const float* pt = Pt + (int64_t)dst_p[pc] * V + 4 * q;
-    f32x4v h[MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
       f32x4v s = *(const f32x4v*)(ps + 16 * a) + *(const f32x4v*)(pt + 16 * a);
 #pragma unroll
       for (int j = 0; j < 4; ++j) h[a][j] = lcao_silu(s[j]);
+    }
+    const int64_t pn = min((tile + stride) * 16 + r, E - 1);
+    sn = src_p[pn];
+    dn = dst_p[pn];
+  }
+  for (; tile < n_tiles; tile += stride) {
+    asm volatile("" ::: "memory");
+    const int64_t p = tile * 16 + r;
+    const bool valid = p < E;
+    const bool more = tile + stride < n_tiles;
+    f32x4v ns[MT], nt[MT];
+    if (more) {
+      const float* ps = Ps + (int64_t)sn * V + 4 * q;
+      const float* pt = Pt + (int64_t)dn * V + 4 * q;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) ns[a] = *(const f32x4v*)(ps + 16 * a);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) nt[a] = *(const f32x4v*)(pt + 16 * a);
+      const int64_t pn2 = min((tile + 2 * stride) * 16 + r, E - 1);
+      sn = src_p[pn2];
+      dn = dst_p[pn2];
     }
     f32x4v o[MT];
 #pragma unroll
@@ -629,6 +670,14 @@ __global__ __launch_bounds__(256) void k_edge_node_message(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] *= lcao_silu(o[m][j]);
         *(f32x4v*)(msg + p * V + 16 * m + 4 * q) = w;
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        f32x4v s = ns[a] + nt[a];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[a][j] = lcao_silu(s[j]);
       }
     }
   }
@@ -644,9 +693,9 @@ static int set_lds_attr(KernelT kern, size_t lds, bool& done) {
   return LCAO_OK;
 }
 
-static unsigned persistent_groups(int64_t n_rows, size_t lds) {
+static unsigned persistent_groups(int64_t n_rows, size_t lds, int waves = 4) {
   int64_t tiles = (n_rows + 15) / 16;
-  int64_t groups = (tiles + 3) / 4;
+  int64_t groups = (tiles + waves - 1) / waves;
   int64_t per_cu = (lds > 80 * 1024) ? 1 : ((lds > 53 * 1024) ? 2 : 3);
   int64_t cap = (int64_t)lcao_num_cu() * per_cu;
   return unsigned(groups > cap ? cap : groups);
@@ -662,11 +711,13 @@ extern "C" int lcao_edge_lcao_weight(const float* tbw, const float* B, const flo
   size_t lds = size_t(2) * V * (V + 4) * sizeof(float);
 #define LW_CASE(V_)                                                                                          \
   if (V == V_) {                                                                                             \
+    /* one workgroup per CU when the two weight matrices fill the LDS: 8 waves keep 2 per SIMD */           \
+    constexpr int TH = (2 * V_ * (V_ + 4) * 4 > 80 * 1024) ? 512 : 256;                                      \
     static bool done = false;                                                                                \
-    int rc = set_lds_attr(k_edge_lcao_weight<V_>, lds, done);                                                \
+    int rc = set_lds_attr(k_edge_lcao_weight<V_, TH>, lds, done);                                            \
     if (rc != LCAO_OK) return rc;                                                                            \
-    hipLaunchKernelGGL(k_edge_lcao_weight<V_>, dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, tbw, B, \
-                       W3, Wb, n_edges, bw);                                                                 \
+    hipLaunchKernelGGL((k_edge_lcao_weight<V_, TH>), dim3(persistent_groups(n_edges, lds, TH / 64)), dim3(TH), lds, \
+                       st, tbw, B, W3, Wb, n_edges, bw);                                                     \
     return lcao_launch_status();                                                                             \
   }
   LW_CASE(128) LW_CASE(64) LW_CASE(32)
