@@ -464,6 +464,33 @@ __global__ void k_embed_coeffs(const float* __restrict__ FE, const float* __rest
   }
 }
 
+// 16-byte form (C % 4 == 0): the D*C/4 float4 slots of an edge are spread over the wave, streaming stores
+__global__ void k_embed_coeffs_v4(const float* __restrict__ FE, const float* __restrict__ U,
+                                  const float* __restrict__ Vt, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const int64_t* __restrict__ z,
+                                  const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, int64_t E,
+                                  int D, int C, float* __restrict__ cst) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int c4n = C >> 2, slots = D * c4n;
+  int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; p < E; p += nwave) {
+    const int64_t zs = z[src_p[p]], zt = z[dst_p[p]];
+    const f4* fe = (const f4*)(FE + zt * D * C);
+    const f4* u = (const f4*)(U + zs * C);
+    const f4* v = (const f4*)(Vt + zt * C);
+    f4* out = (f4*)(cst + p * (int64_t)D * C);
+    for (int i = lane; i < slots; i += 64) {
+      const int c4 = i % c4n;
+      const f4 zz = u[c4] + v[c4];
+      const f4 e = fe[i];
+      const f4 o = (e + e * zz) * ((const f4*)scale)[i] + ((const f4*)shift)[i];
+      __builtin_nontemporal_store(o, out + i);
+    }
+  }
+}
+
 extern "C" int lcao_embed_coeffs(const float* FE, const float* U, const float* Vt, const float* scale,
                                  const float* shift, const int64_t* z, const int32_t* src_p, const int32_t* dst_p,
                                  int64_t n_edges, int n_orb, int C, float* cst, void* stream) {
@@ -472,8 +499,14 @@ extern "C" int lcao_embed_coeffs(const float* FE, const float* U, const float* V
   if (n_edges == 0) return LCAO_OK;
   LCAO_CHECK_PTR(FE); LCAO_CHECK_PTR(U); LCAO_CHECK_PTR(Vt); LCAO_CHECK_PTR(scale); LCAO_CHECK_PTR(shift);
   LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(cst);
-  hipLaunchKernelGGL(k_embed_coeffs, dim3(lcao_blocks(n_edges, 4, 32768)), dim3(256), 0, (hipStream_t)stream, FE, U,
-                     Vt, scale, shift, z, src_p, dst_p, n_edges, n_orb, C, cst);
+  const bool v4 = (C % 4 == 0) && (((uintptr_t)FE | (uintptr_t)U | (uintptr_t)Vt | (uintptr_t)scale |
+                                     (uintptr_t)shift | (uintptr_t)cst) % 16 == 0);
+  if (v4)
+    hipLaunchKernelGGL(k_embed_coeffs_v4, dim3(lcao_blocks(n_edges, 4, 32768)), dim3(256), 0, (hipStream_t)stream, FE,
+                       U, Vt, scale, shift, z, src_p, dst_p, n_edges, n_orb, C, cst);
+  else
+    hipLaunchKernelGGL(k_embed_coeffs, dim3(lcao_blocks(n_edges, 4, 32768)), dim3(256), 0, (hipStream_t)stream, FE, U,
+                       Vt, scale, shift, z, src_p, dst_p, n_edges, n_orb, C, cst);
   return lcao_launch_status();
 }
 

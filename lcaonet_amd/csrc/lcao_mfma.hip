@@ -659,14 +659,19 @@ __global__ __launch_bounds__(256) void k_edge_node_message(const float* __restri
       sn = src_p[pn2];
       dn = dst_p[pn2];
     }
-    f32x4v o[MT];
+    f32x4v o[MT], wv[MT];
+    const int64_t pw = valid ? p : E - 1;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wv[m] = *(const f32x4v*)(bw + pw * V + 16 * m + 4 * q);  // in flight under the GEMM
 #pragma unroll
     for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);  // bias as the initial accumulator
+    __builtin_amdgcn_s_setprio(1);  // the wave on the matrix cores outranks its SIMD partner's SiLU phase
     mfma_layer<MT, MT>(lds, V + 4, r, q, h, o);
+    __builtin_amdgcn_s_setprio(0);
     if (valid) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        f32x4v w = *(const f32x4v*)(bw + p * V + 16 * m + 4 * q);
+        f32x4v w = wv[m];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] *= lcao_silu(o[m][j]);
         *(f32x4v*)(msg + p * V + 16 * m + 4 * q) = w;
