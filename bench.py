@@ -34,6 +34,11 @@ WORKLOADS = {
     # one rank's share (1/8) of BASELINE config 4: a 63^3 = 250 047-atom periodic crystal, cutoff 6.0, 32 nearest neighbours
     "cfg4-1of8": (dict(crystal=True, n_side=63, a=3.2, sigma=0.05, cutoff_graph=5.94, max_neighbors=32, max_z=36),
                   dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=6.0)),
+    # one rank's share (1/8) of BASELINE config 5: 16 250 QM9-shaped molecules (3..29 atoms, z in {1,6,7,8,9}), cutoff 6.0,
+    # hidden 256, 6 interactions, energy + forces via the reverse sweep (regress_forces=True, direct_forces=False)
+    "cfg5-1of8": (dict(molecules=True, n_mol=16250, cutoff_graph=5.94),
+                  dict(emb_size=256, emb_size_coeff=128, emb_size_conv=128, n_interaction=6, cutoff=6.0, max_z=10,
+                       regress_forces=True, direct_forces=False)),
     "cfg2-small": (dict(n_cells=64, n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, max_z=36),
                    dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=5.0)),
 }
@@ -144,6 +149,9 @@ def main():
         ck = {k: v for k, v in gen_kw.items() if k != "crystal"}
         batch = jittered_cubic_crystal(seed=1234 + rank, device=dev, **ck)
         gen_kw = dict(gen_kw, n_cells=1)
+    elif gen_kw.get("molecules"):
+        from lcaonet_amd.data.synthetic import random_molecule_batch
+        batch = random_molecule_batch(gen_kw["n_mol"], cutoff_graph=gen_kw["cutoff_graph"], seed=1234 + rank, device=dev)
     else:
         batch = jittered_cubic_cells(seed=1234 + rank, device=dev, **gen_kw)  # this rank's own crystals
     E = int(batch["edge_index"].shape[1])
@@ -169,6 +177,10 @@ def main():
             barrier()
             elapsed = time.perf_counter() - t0
             ksum = prof.summary()
+    with_forces = isinstance(out, tuple)
+    if with_forces:
+        assert bool(torch.isfinite(out[1]).all())
+        out = out[0]
     assert bool(torch.isfinite(out).all())
     t = torch.tensor([elapsed, float(E)], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if dist is not None:
@@ -202,9 +214,13 @@ def main():
                 for _ in range(args.steps):
                     model(batch, fused=fused)
                 kall = prof_all.summary()
+            if with_forces:
+                raise StopIteration
             pair_ms, pair_err = timed(cst_mode="pair")                       # species-pair table
             bf_ms, bf_err = timed(precision="bf16x3")                        # BASELINE config 3
             bp_ms, bp_err = timed(precision="bf16x3", cst_mode="pair")
+        except StopIteration:
+            pass
         except Exception as e:  # noqa: BLE001
             secondary_error = f"{type(e).__name__}: {e}"
 
@@ -238,15 +254,18 @@ def main():
                         "traffic": pmc_traffic("lcao_triplet_gemm") if args.workload == "cfg2" else None,
                         "avg_launch_ms": round(per_launch_ms, 4), "launches": calls,
                         "algorithmic_bytes_per_launch": byts}
+        shape = (f"{gen_kw['n_mol']} random molecules of 3..29 atoms" if gen_kw.get("molecules") else
+                 f"{gen_kw['n_cells']} jittered {gen_kw['n_side']}^3 simple-cubic crystals")
         line = {
             "metric": "edges/sec forward (LCAOConv stack), 1M-edge synthetic batch",
             "value": e_total * args.steps / elapsed_max, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {gen_kw['n_cells']} jittered {gen_kw['n_side']}^3 simple-cubic "
-                                   f"crystals per GPU (N={N}, E={E} per GPU), graph cutoff {gen_kw['cutoff_graph']}, "
+            "config": {"workload": f"{args.workload}: {shape} per GPU (N={N}, E={E} per GPU), graph cutoff "
+                                   f"{gen_kw['cutoff_graph']}, "
                                    f"LCAONet(emb_size={model.emb_size}, coeff={C}, conv={V}, n_interaction={L}, D={D}, "
-                                   f"cutoff={model.cutoff}), random-init weights, eval, whole forward",
+                                   f"cutoff={model.cutoff}), random-init weights, eval, whole forward"
+                                   + (" + forces = -dE/dpos (reverse sweep)" if with_forces else ""),
                        "edges_per_gpu": E, "nodes_per_gpu": N, "sharding": "whole crystals per rank, no collective"},
             "roofline": roof, "roofline_hbm": roof_hbm,
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kall.items(), key=lambda kv: -kv[1][1])},
