@@ -203,6 +203,14 @@ int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, co
                            const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
                            float* msg, void* stream);
 
+/* The same two kernels for a forward pass that will be differentiated (autograd forces, training): they also keep
+ * ft = tbw W3^T (E,V) and pre2 = SiLU(Ps[s]+Pt[t]) Wn2^T + bn2 (E,V), the two intermediates the reverse sweep needs. */
+int lcao_edge_lcao_weight_saving(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges,
+                                 int V, float* bw, float* ft, void* stream);
+int lcao_edge_node_message_saving(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                  const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
+                                  float* msg, float* pre2, void* stream);
+
 /* ---- activation-gradient kernels for autograd forces at inference (lcaonet/model/lcaonet.py:310-317).
  * g_X = dE/dX.  Dense layers are differentiated by lcao_dense on transposed weights; see csrc/lcao_backward.hip. ---- */
 int lcao_act_bwd(const float* g, const float* pre, int64_t n, int act, float* out, void* stream);
@@ -212,6 +220,17 @@ int lcao_message_bwd(const float* g_agg, const int32_t* src_p, const float* bw, 
                      float* g_bw, float* g_pre2, void* stream);
 int lcao_combine_bwd(const float* g_lw, const float* B, const float* ft, int64_t n_edges, int V, float* g_B, float* g_ft,
                      void* stream);
+/* Fused MFMA forms of the two-body reverse sweep (V in {32, 64, 128}; what torch.autograd does for lcaonet.py:192-213).
+ * lcao_message_bwd_fused = lcao_message_bwd + Dense^T(f_node.2) + SiLU'(pre1), pre1 = Ps[src_p] + Pt[dst_p] recomputed:
+ *   g_bw = g_agg[src_p] SiLU(pre2);  g_pre2 = g_agg[src_p] bw SiLU'(pre2);  g_pre1 = (g_pre2 Wn2) SiLU'(pre1)
+ *   Wn2T = Wn2^T (V,V) contiguous;  g_pre2 (E,V) is written only when non-NULL (weight gradients need it).
+ * lcao_lcao_weight_bwd_fused = Dense^T(basis_weight) + lcao_combine_bwd + Dense^T(f_three):
+ *   g_lw = g_bw Wb;  (g_B, g_ft) as lcao_combine_bwd;  g_tbw = g_ft W3;   WbT = Wb^T, W3T = W3^T;  g_ft optional. */
+int lcao_message_bwd_fused(const float* g_agg, const int32_t* src_p, const int32_t* dst_p, const float* bw,
+                           const float* pre2, const float* Ps, const float* Pt, const float* Wn2T, int64_t n_edges,
+                           int V, float* g_bw, float* g_pre1, float* g_pre2, void* stream);
+int lcao_lcao_weight_bwd_fused(const float* g_bw, const float* B, const float* ft, const float* WbT, const float* W3T,
+                               int64_t n_edges, int V, float* g_B, float* g_tbw, float* g_ft, void* stream);
 /* three-body backward: g_tbw -> g_Ag, g_gram (per in-edge), g_uq / g_up (dE/d unit vector as in-edge / out-edge);
  * tbase[s] = offset of node s in the (sum_s m_in*m_out) float scratch `gc_scratch` */
 int lcao_triplet_bwd(const float* g_tbw, const float* Ag, const float* gram, const float* uvec_p, const int32_t* src_p,

@@ -8,12 +8,6 @@
 // owned by exactly one wave, or goes through a dense per-node scratch matrix that a second kernel sums in fixed order.
 #include "lcao_common.h"
 
-__device__ __forceinline__ float lcao_silu_grad(float x) {
-  // d/dx [x sigmoid(x)] = s (1 + x (1 - s))
-  const float s = lcao_sigmoid(x);
-  return s * (1.0f + x * (1.0f - s));
-}
-
 // out = g * silu'(pre)                      (act == SILU)
 // out = g * s (1 - s), s = sigmoid(pre)     (act == SIGMOID)
 __global__ void k_act_bwd(const float* __restrict__ g, const float* __restrict__ pre, int64_t n, int act,

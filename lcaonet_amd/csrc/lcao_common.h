@@ -37,7 +37,14 @@ __device__ __forceinline__ float lcao_silu(float x) {
   // Tails: x -> -inf gives exp = inf, rcp = 0, result -0 (never NaN for finite x).
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
+
 __device__ __forceinline__ float lcao_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float lcao_silu_grad(float x) {
+  // d/dx [x sigmoid(x)] = s (1 + x (1 - s))
+  const float s = lcao_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
 
 __device__ __forceinline__ float lcao_act(float x, int act) {
   if (act == LCAO_ACT_SILU) return lcao_silu(x);

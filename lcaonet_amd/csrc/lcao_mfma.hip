@@ -536,7 +536,8 @@ __global__ __launch_bounds__(THREADS) void k_edge_lcao_weight(const float* __res
                                                               const float* __restrict__ B,
                                                               const float* __restrict__ W3,
                                                               const float* __restrict__ Wb, int64_t E,
-                                                              float* __restrict__ bw) {
+                                                              float* __restrict__ bw,
+                                                              float* __restrict__ ft_out /* or null */) {
   constexpr int MT = V / 16, WAVES = THREADS / 64;
   extern __shared__ float lds[];
   float* w3s = lds;
@@ -569,6 +570,10 @@ __global__ __launch_bounds__(THREADS) void k_edge_lcao_weight(const float* __res
 #pragma unroll
     for (int m = 0; m < MT; ++m) ft[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
     mfma_layer<MT, MT>(w3s, V + 4, r, q, x, ft);
+    if (ft_out && valid) {  // kept for the reverse sweep (forces / training)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *(f32x4v*)(ft_out + p * V + 16 * m + 4 * q) = ft[m];
+    }
     if (nxt < n_tiles) {
 #pragma unroll
       for (int a = 0; a < MT; ++a) x[a] = *(const f32x4v*)(tbw + pn * V + 16 * a + 4 * q);
@@ -614,7 +619,8 @@ __global__ __launch_bounds__(256) void k_edge_node_message(const float* __restri
                                                            const int32_t* __restrict__ dst_p,
                                                            const float* __restrict__ Wn2,
                                                            const float* __restrict__ bn2, int64_t E,
-                                                           float* __restrict__ msg) {
+                                                           float* __restrict__ msg,
+                                                           float* __restrict__ pre2_out /* or null */) {
   constexpr int MT = V / 16;
   extern __shared__ float lds[];
   stage_weights(lds, Wn2, V, V, V);
@@ -672,6 +678,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message(const float* __restri
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         f32x4v w = wv[m];
+        if (pre2_out) *(f32x4v*)(pre2_out + p * V + 16 * m + 4 * q) = o[m];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w[j] *= lcao_silu(o[m][j]);
         *(f32x4v*)(msg + p * V + 16 * m + 4 * q) = w;
@@ -706,8 +713,8 @@ static unsigned persistent_groups(int64_t n_rows, size_t lds, int waves = 4) {
   return unsigned(groups > cap ? cap : groups);
 }
 
-extern "C" int lcao_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb,
-                                     int64_t n_edges, int V, float* bw, void* stream) {
+static int launch_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges,
+                                   int V, float* bw, float* ft_out, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   if (V <= 0) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
@@ -722,7 +729,7 @@ extern "C" int lcao_edge_lcao_weight(const float* tbw, const float* B, const flo
     int rc = set_lds_attr(k_edge_lcao_weight<V_, TH>, lds, done);                                            \
     if (rc != LCAO_OK) return rc;                                                                            \
     hipLaunchKernelGGL((k_edge_lcao_weight<V_, TH>), dim3(persistent_groups(n_edges, lds, TH / 64)), dim3(TH), lds, \
-                       st, tbw, B, W3, Wb, n_edges, bw);                                                     \
+                       st, tbw, B, W3, Wb, n_edges, bw, ft_out);                                             \
     return lcao_launch_status();                                                                             \
   }
   LW_CASE(128) LW_CASE(64) LW_CASE(32)
@@ -730,9 +737,20 @@ extern "C" int lcao_edge_lcao_weight(const float* tbw, const float* B, const flo
   return LCAO_ERR_UNSUPPORTED;
 }
 
-extern "C" int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
-                                      const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges,
-                                      int V, float* msg, void* stream) {
+extern "C" int lcao_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb,
+                                     int64_t n_edges, int V, float* bw, void* stream) {
+  return launch_edge_lcao_weight(tbw, B, W3, Wb, n_edges, V, bw, nullptr, stream);
+}
+
+extern "C" int lcao_edge_lcao_weight_saving(const float* tbw, const float* B, const float* W3, const float* Wb,
+                                            int64_t n_edges, int V, float* bw, float* ft, void* stream) {
+  if (n_edges > 0) LCAO_CHECK_PTR(ft);
+  return launch_edge_lcao_weight(tbw, B, W3, Wb, n_edges, V, bw, ft, stream);
+}
+
+static int launch_edge_node_message(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                    const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
+                                    float* msg, float* pre2_out, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   if (V <= 0) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
@@ -746,11 +764,214 @@ extern "C" int lcao_edge_node_message(const float* bw, const float* Ps, const fl
     int rc = set_lds_attr(k_edge_node_message<V_>, lds, done);                                                 \
     if (rc != LCAO_OK) return rc;                                                                              \
     hipLaunchKernelGGL(k_edge_node_message<V_>, dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, bw, Ps, \
-                       Pt, src_p, dst_p, Wn2, bn2, n_edges, msg);                                              \
+                       Pt, src_p, dst_p, Wn2, bn2, n_edges, msg, pre2_out);                                    \
     return lcao_launch_status();                                                                               \
   }
   NM_CASE(128) NM_CASE(64) NM_CASE(32)
 #undef NM_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}
+
+extern "C" int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                      const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges,
+                                      int V, float* msg, void* stream) {
+  return launch_edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, n_edges, V, msg, nullptr, stream);
+}
+
+extern "C" int lcao_edge_node_message_saving(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                             const int32_t* dst_p, const float* Wn2, const float* bn2,
+                                             int64_t n_edges, int V, float* msg, float* pre2, void* stream) {
+  if (n_edges > 0) LCAO_CHECK_PTR(pre2);
+  return launch_edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, n_edges, V, msg, pre2, stream);
+}
+
+// ===================================================================================================
+// Reverse sweep of the two-body chain (autograd forces / training), fused like the forward kernels.
+//
+// lcao_message_bwd_fused — backward of  msg = bw * SiLU(pre2),  pre2 = Wn2 . SiLU(pre1) + b,  pre1 = Ps[s] + Pt[t]:
+//   g_msg = g_agg[src_p];  g_bw = g_msg SiLU(pre2);  g_pre2 = g_msg bw SiLU'(pre2)
+//   g_pre1 = (Wn2^T . g_pre2) SiLU'(pre1)                                   weights: Wn2T = Wn2^T (V, V) row-major
+// lcao_lcao_weight_bwd_fused — backward of  bw = Wb . lw,  lw = u / max(|u|, eps),  u = B (1 + ft),  ft = W3 . tbw:
+//   g_lw = Wb^T . g_bw;  g_u = (g_lw - lw (lw . g_lw)) / |u|;  g_B = g_u (1 + ft);  g_ft = g_u B;  g_tbw = W3^T . g_ft
+// Same tile formulation as the forward kernels (gradient rows are the MFMA B operand, transposed weights in LDS).
+// ===================================================================================================
+template <int V>
+__global__ __launch_bounds__(256) void k_message_bwd_mfma(
+    const float* __restrict__ g_agg, const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p,
+    const float* __restrict__ bw, const float* __restrict__ pre2, const float* __restrict__ Ps,
+    const float* __restrict__ Pt, const float* __restrict__ Wn2T, int64_t E, float* __restrict__ g_bw,
+    float* __restrict__ g_pre1, float* __restrict__ g_pre2_out /* or null */) {
+  constexpr int MT = V / 16;
+  extern __shared__ float lds[];
+  stage_weights(lds, Wn2T, V, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (E + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");
+    const int64_t p = tile * 16 + r;
+    const bool valid = p < E;
+    const int64_t pc = valid ? p : E - 1;
+    const int s = src_p[pc], t = dst_p[pc];
+    const float* ga = g_agg + (int64_t)s * V + 4 * q;
+    f32x4v gp2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const f32x4v g = *(const f32x4v*)(ga + 16 * m);
+      const f32x4v b = *(const f32x4v*)(bw + pc * V + 16 * m + 4 * q);
+      const f32x4v x = *(const f32x4v*)(pre2 + pc * V + 16 * m + 4 * q);
+      f32x4v gb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gb[j] = g[j] * lcao_silu(x[j]);
+        gp2[m][j] = g[j] * b[j] * lcao_silu_grad(x[j]);
+      }
+      if (valid) {
+        *(f32x4v*)(g_bw + p * V + 16 * m + 4 * q) = gb;
+        if (g_pre2_out) *(f32x4v*)(g_pre2_out + p * V + 16 * m + 4 * q) = gp2[m];
+      }
+    }
+    f32x4v gh[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) gh[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    mfma_layer<MT, MT>(lds, V + 4, r, q, gp2, gh);
+    if (valid) {
+      const float* ps = Ps + (int64_t)s * V + 4 * q;
+      const float* pt = Pt + (int64_t)t * V + 4 * q;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const f32x4v x1 = *(const f32x4v*)(ps + 16 * m) + *(const f32x4v*)(pt + 16 * m);
+        f32x4v o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gh[m][j] * lcao_silu_grad(x1[j]);
+        *(f32x4v*)(g_pre1 + p * V + 16 * m + 4 * q) = o;
+      }
+    }
+  }
+}
+
+template <int V, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_lcao_weight_bwd_mfma(
+    const float* __restrict__ g_bw, const float* __restrict__ B, const float* __restrict__ ft,
+    const float* __restrict__ WbT, const float* __restrict__ W3T, int64_t E, float* __restrict__ g_B,
+    float* __restrict__ g_tbw, float* __restrict__ g_ft_out /* or null */) {
+  constexpr int MT = V / 16, WAVES = THREADS / 64;
+  extern __shared__ float lds[];
+  float* wbs = lds;
+  float* w3s = lds + V * (V + 4);
+  stage_weights(wbs, WbT, V, V, V);
+  stage_weights(w3s, W3T, V, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (E + 15) >> 4;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+    asm volatile("" ::: "memory");
+    const int64_t p = tile * 16 + r;
+    const bool valid = p < E;
+    const int64_t pc = valid ? p : E - 1;
+    f32x4v x[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) x[a] = *(const f32x4v*)(g_bw + pc * V + 16 * a + 4 * q);
+    f32x4v gl[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) gl[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    mfma_layer<MT, MT>(wbs, V + 4, r, q, x, gl);
+    f32x4v b[MT], f[MT];
+    float n2 = 0.f, dot = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      b[m] = *(const f32x4v*)(B + pc * V + 16 * m + 4 * q);
+      f[m] = *(const f32x4v*)(ft + pc * V + 16 * m + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = b[m][j] + b[m][j] * f[m][j];
+        x[m][j] = u;  // x is free after the first GEMM: keep u there
+        n2 += u * u;
+        dot += u * gl[m][j];
+      }
+    }
+    n2 += __shfl_xor(n2, 16);
+    n2 += __shfl_xor(n2, 32);
+    dot += __shfl_xor(dot, 16);
+    dot += __shfl_xor(dot, 32);
+    const float nrm = sqrtf(n2);
+    const bool live = nrm > 1e-12f;
+    const float inv = live ? 1.0f / nrm : 1e12f;
+    const float proj = live ? dot * inv * inv : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4v gB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gu = inv * (gl[m][j] - x[m][j] * proj);
+        gB[j] = gu * (1.0f + f[m][j]);
+        gl[m][j] = gu * b[m][j];  // g_ft, the operand of the second GEMM
+      }
+      if (valid) {
+        *(f32x4v*)(g_B + p * V + 16 * m + 4 * q) = gB;
+        if (g_ft_out) *(f32x4v*)(g_ft_out + p * V + 16 * m + 4 * q) = gl[m];
+      }
+    }
+    f32x4v o[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    mfma_layer<MT, MT>(w3s, V + 4, r, q, gl, o);
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *(f32x4v*)(g_tbw + p * V + 16 * m + 4 * q) = o[m];
+    }
+  }
+}
+
+extern "C" int lcao_message_bwd_fused(const float* g_agg, const int32_t* src_p, const int32_t* dst_p, const float* bw,
+                                      const float* pre2, const float* Ps, const float* Pt, const float* Wn2T,
+                                      int64_t n_edges, int V, float* g_bw, float* g_pre1, float* g_pre2,
+                                      void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_agg); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(pre2);
+  LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(Wn2T); LCAO_CHECK_PTR(g_bw); LCAO_CHECK_PTR(g_pre1);
+  hipStream_t st = (hipStream_t)stream;
+  size_t lds = size_t(V) * (V + 4) * sizeof(float);
+#define MB_CASE(V_)                                                                                              \
+  if (V == V_) {                                                                                                 \
+    static bool done = false;                                                                                    \
+    int rc = set_lds_attr(k_message_bwd_mfma<V_>, lds, done);                                                    \
+    if (rc != LCAO_OK) return rc;                                                                                \
+    hipLaunchKernelGGL(k_message_bwd_mfma<V_>, dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, g_agg,  \
+                       src_p, dst_p, bw, pre2, Ps, Pt, Wn2T, n_edges, g_bw, g_pre1, g_pre2);                     \
+    return lcao_launch_status();                                                                                 \
+  }
+  MB_CASE(128) MB_CASE(64) MB_CASE(32)
+#undef MB_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}
+
+extern "C" int lcao_lcao_weight_bwd_fused(const float* g_bw, const float* B, const float* ft, const float* WbT,
+                                          const float* W3T, int64_t n_edges, int V, float* g_B, float* g_tbw,
+                                          float* g_ft, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_bw); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(ft); LCAO_CHECK_PTR(WbT); LCAO_CHECK_PTR(W3T);
+  LCAO_CHECK_PTR(g_B); LCAO_CHECK_PTR(g_tbw);
+  hipStream_t st = (hipStream_t)stream;
+  size_t lds = size_t(2) * V * (V + 4) * sizeof(float);
+#define WB_CASE(V_)                                                                                              \
+  if (V == V_) {                                                                                                 \
+    constexpr int TH = (2 * V_ * (V_ + 4) * 4 > 80 * 1024) ? 512 : 256;                                          \
+    static bool done = false;                                                                                    \
+    int rc = set_lds_attr(k_lcao_weight_bwd_mfma<V_, TH>, lds, done);                                            \
+    if (rc != LCAO_OK) return rc;                                                                                \
+    hipLaunchKernelGGL((k_lcao_weight_bwd_mfma<V_, TH>), dim3(persistent_groups(n_edges, lds, TH / 64)), dim3(TH), \
+                       lds, st, g_bw, B, ft, WbT, W3T, n_edges, g_B, g_tbw, g_ft);                               \
+    return lcao_launch_status();                                                                                 \
+  }
+  WB_CASE(128) WB_CASE(64) WB_CASE(32)
+#undef WB_CASE
   return LCAO_ERR_UNSUPPORTED;
 }
 

@@ -46,15 +46,24 @@ def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim)
                    None, ACT)
     Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
     tbw = ops.triplet_gemm(Ag, gram, uvec_p, ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
-    ft = ops.dense(tbw, layer.f_three[0].weight.detach())
-    lw = ops.edge_combine(ft, B, None)
-    bw = ops.dense(lw, layer.basis_weight.weight.detach())
-    pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
-    h1 = torch.nn.functional.silu(pre1)
-    pre2 = ops.dense(h1, layer.f_node[2].weight.detach(), layer.f_node[2].bias.detach())
-    agg = ops.segment_sum(bw, ctx.out_ptr, torch.nn.functional.silu(pre2))
+    if V in ops.FUSED_WIDTHS:
+        # the forward's fused two-body kernels, keeping ft and pre2; pre1 = Ps[s] + Pt[t] is recomputed in the sweep
+        bw, ft = ops.edge_lcao_weight(tbw, B, layer.f_three[0].weight.detach(), layer.basis_weight.weight.detach(),
+                                      save=True)
+        msg, pre2 = ops.edge_node_message(bw, Ps, Pt, ctx.src_p, ctx.dst_p, layer.f_node[2].weight.detach(),
+                                          layer.f_node[2].bias.detach(), save=True)
+        agg = ops.segment_sum(msg, ctx.out_ptr)
+        pre1 = None
+    else:
+        ft = ops.dense(tbw, layer.f_three[0].weight.detach())
+        lw = ops.edge_combine(ft, B, None)
+        bw = ops.dense(lw, layer.basis_weight.weight.detach())
+        pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
+        h1 = torch.nn.functional.silu(pre1)
+        pre2 = ops.dense(h1, layer.f_node[2].weight.detach(), layer.f_node[2].bias.detach())
+        agg = ops.segment_sum(bw, ctx.out_ptr, torch.nn.functional.silu(pre2))
     x_new = ops.dense(agg, layer.out_weight.weight.detach(), None, ops.ACT_NONE, x)
-    saved = dict(xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, ft=ft, bw=bw, pre1=pre1, pre2=pre2)
+    saved = dict(xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, ft=ft, bw=bw, pre1=pre1, pre2=pre2, Ps=Ps, Pt=Pt)
     return x_new, saved
 
 
@@ -66,15 +75,21 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     # x' = x + agg Wout^T
     g_agg = ops.dense(g_xnew, _t(layer.out_weight.weight))
     # msg = bw * silu(pre2), agg = segment sum
-    g_bw, g_pre2 = ops.message_bwd(g_agg, ctx.src_p, sv["bw"], sv["pre2"])
-    g_h1 = ops.dense(g_pre2, _t(layer.f_node[2].weight))
-    g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
+    # bw = lw Wb^T ; lw = normalize(B (1 + ft)) ; ft = tbw W3^T
+    if V in ops.FUSED_WIDTHS:
+        g_bw, g_pre1, _ = ops.message_bwd_fused(g_agg, ctx.src_p, ctx.dst_p, sv["bw"], sv["pre2"], sv["Ps"], sv["Pt"],
+                                                _t(layer.f_node[2].weight))
+        g_B, g_tbw, _ = ops.lcao_weight_bwd_fused(g_bw, sv["B"], sv["ft"], _t(layer.basis_weight.weight),
+                                                  _t(layer.f_three[0].weight))
+    else:
+        g_bw, g_pre2 = ops.message_bwd(g_agg, ctx.src_p, sv["bw"], sv["pre2"])
+        g_h1 = ops.dense(g_pre2, _t(layer.f_node[2].weight))
+        g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
+        g_lw = ops.dense(g_bw, _t(layer.basis_weight.weight))
+        g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
+        g_tbw = ops.dense(g_ft, _t(layer.f_three[0].weight))
     g_Ps = ops.segment_sum(g_pre1, ctx.out_ptr)          # pre1 = Ps[src] + Pt[dst]
     g_Pt = _in_sum(g_pre1, ctx, N)
-    # bw = lw Wb^T ; lw = normalize(B (1 + ft)) ; ft = tbw W3^T
-    g_lw = ops.dense(g_bw, _t(layer.basis_weight.weight))
-    g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
-    g_tbw = ops.dense(g_ft, _t(layer.f_three[0].weight))
     # three-body term
     g_Ag, g_gram, g_uq, g_up = ops.triplet_bwd(g_tbw, sv["Ag"], sv["gram"], uvec_p, ctx.src_p, ctx.dst_p, ctx.in_ptr,
                                                ctx.in_pos, ctx.out_ptr, tbase, n_trip_dense, E, N)

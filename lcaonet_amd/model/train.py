@@ -158,16 +158,22 @@ class LCAOStackFn(torch.autograd.Function):
             Tf = Tfs[i].detach().contiguous()
             Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, gate, geom.n_l, geom.zd)
             tbw = ops.triplet_gemm(Ag, gram, geom.uvec_p, ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
-            ft = ops.dense(tbw, W3)
-            lw = ops.edge_combine(ft, B, None)
-            bw = ops.dense(lw, Wb)
-            pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
-            h1 = F.silu(pre1)
-            pre2 = ops.dense(h1, Wn2, bn2)
-            agg = ops.segment_sum(bw, ctx.out_ptr, F.silu(pre2))
+            if V in ops.FUSED_WIDTHS:
+                bw, ft = ops.edge_lcao_weight(tbw, B, W3, Wb, save=True)
+                msg, pre2 = ops.edge_node_message(bw, Ps, Pt, ctx.src_p, ctx.dst_p, Wn2, bn2, save=True)
+                agg = ops.segment_sum(msg, ctx.out_ptr)
+                pre1 = None
+            else:
+                ft = ops.dense(tbw, W3)
+                lw = ops.edge_combine(ft, B, None)
+                bw = ops.dense(lw, Wb)
+                pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
+                h1 = F.silu(pre1)
+                pre2 = ops.dense(h1, Wn2, bn2)
+                agg = ops.segment_sum(bw, ctx.out_ptr, F.silu(pre2))
             x_new = ops.dense(agg, Wout, None, ops.ACT_NONE, x)
             saved.append(dict(x=x, xs=xs, xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, tbw=tbw, ft=ft, bw=bw,
-                              pre1=pre1, pre2=pre2, agg=agg))
+                              pre1=pre1, pre2=pre2, agg=agg, Ps=Ps, Pt=Pt))
             x = x_new
         fctx.geom, fctx.n_layers, fctx.saved = geom, n_layers, saved
         fctx.params = [p.detach() for p in params]
@@ -196,20 +202,32 @@ class LCAOStackFn(torch.autograd.Function):
             # x' = x + agg Wout^T
             gp[i * 9 + 8] = _mm_t(g_x, sv["agg"])
             g_agg = ops.dense(g_x, Wout.t().contiguous())
-            g_bw, g_pre2 = ops.message_bwd(g_agg, ctx.src_p, sv["bw"], sv["pre2"])
-            h1 = F.silu(sv["pre1"])
+            fused = V in ops.FUSED_WIDTHS
+            if fused:
+                g_bw, g_pre1, g_pre2 = ops.message_bwd_fused(g_agg, ctx.src_p, ctx.dst_p, sv["bw"], sv["pre2"], sv["Ps"],
+                                                             sv["Pt"], Wn2.t().contiguous(), want_g_pre2=True)
+                h1 = ops.pair_silu(sv["Ps"], sv["Pt"], ctx.src_p, ctx.dst_p)
+            else:
+                g_bw, g_pre2 = ops.message_bwd(g_agg, ctx.src_p, sv["bw"], sv["pre2"])
+                h1 = F.silu(sv["pre1"])
+                g_h1 = ops.dense(g_pre2, Wn2.t().contiguous())
+                g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
             gp[i * 9 + 6] = _mm_t(g_pre2, h1)
             gp[i * 9 + 7] = g_pre2.sum(0)
-            g_h1 = ops.dense(g_pre2, Wn2.t().contiguous())
-            g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
+            del h1, g_pre2
             g_Ps = ops.segment_sum(g_pre1, ctx.out_ptr)
             g_Pt = ops.segment_sum(ops.gather_rows(g_pre1, ctx.in_pos), ctx.in_ptr)
             lw = ops.edge_combine(sv["ft"], sv["B"], None)
             gp[i * 9 + 3] = _mm_t(g_bw, lw)
-            g_lw = ops.dense(g_bw, Wb.t().contiguous())
-            g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
+            del lw
+            if fused:
+                g_B, g_tbw, g_ft = ops.lcao_weight_bwd_fused(g_bw, sv["B"], sv["ft"], Wb.t().contiguous(),
+                                                             W3.t().contiguous(), want_g_ft=True)
+            else:
+                g_lw = ops.dense(g_bw, Wb.t().contiguous())
+                g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
+                g_tbw = ops.dense(g_ft, W3.t().contiguous())
             gp[i * 9 + 2] = _mm_t(g_ft, sv["tbw"])
-            g_tbw = ops.dense(g_ft, W3.t().contiguous())
             if V not in ops.FUSED_WIDTHS and n_dense is None:
                 n_dense = int(prod.sum().item())
             g_Ag, g_gram, _, _ = ops.triplet_bwd(g_tbw, sv["Ag"], sv["gram"], geom.uvec_p, ctx.src_p, ctx.dst_p, ctx.in_ptr,

@@ -342,24 +342,57 @@ def triplet_literal(cstf, rb, shb, xk, tri_k, e_ks, mask, V, valence):
     return w
 
 
-def edge_lcao_weight(tbw, B, W3, Wb, precision="fp32"):
+def edge_lcao_weight(tbw, B, W3, Wb, precision="fp32", save=False):
+    """bw, or (bw, ft) with save=True (fp32 only): ft = tbw W3^T is what the reverse sweep needs."""
     tbw, B, W3, Wb = _f32(tbw), _f32(B), _f32(W3), _f32(Wb)
     E, V = B.shape
     bw = torch.empty(E, V, device=B.device, dtype=torch.float32)
+    if save:
+        ft = torch.empty(E, V, device=B.device, dtype=torch.float32)
+        _call("lcao_edge_lcao_weight_saving", _p(tbw), _p(B), _p(W3), _p(Wb), E, V, _p(bw), _p(ft), _stream())
+        return bw, ft
     _call("lcao_edge_lcao_weight_bf16x3" if precision == "bf16x3" else "lcao_edge_lcao_weight", _p(tbw), _p(B), _p(W3), _p(Wb), E, V, _p(bw), _stream())
     return bw
 
 
-def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, precision="fp32"):
+def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, precision="fp32", save=False):
+    """msg, or (msg, pre2) with save=True (fp32 only): pre2 is the pre-activation of the second f_node layer."""
     bw, Ps, Pt, Wn2, bn2 = _f32(bw), _f32(Ps), _f32(Pt), _f32(Wn2), _f32(bn2)
     E, V = bw.shape
     msg = torch.empty(E, V, device=bw.device, dtype=torch.float32)
+    if save:
+        pre2 = torch.empty(E, V, device=bw.device, dtype=torch.float32)
+        _call("lcao_edge_node_message_saving", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V,
+              _p(msg), _p(pre2), _stream())
+        return msg, pre2
     _call("lcao_edge_node_message_bf16x3" if precision == "bf16x3" else "lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg),
                                           _stream())
     return msg
 
 
 # --- activation-gradient kernels (autograd forces at inference; csrc/lcao_backward.hip) -------------------------
+def message_bwd_fused(g_agg, src_p, dst_p, bw, pre2, Ps, Pt, Wn2T, want_g_pre2=False):
+    """(g_bw, g_pre1, g_pre2|None): message product, second f_node layer and SiLU'(pre1) differentiated in one kernel."""
+    g_agg, bw, pre2, Ps, Pt, Wn2T = _f32(g_agg), _f32(bw), _f32(pre2), _f32(Ps), _f32(Pt), _f32(Wn2T)
+    E, V = bw.shape
+    g_bw, g_pre1 = torch.empty_like(bw), torch.empty_like(bw)
+    g_pre2 = torch.empty_like(bw) if want_g_pre2 else None
+    _call("lcao_message_bwd_fused", _p(g_agg), _p(src_p), _p(dst_p), _p(bw), _p(pre2), _p(Ps), _p(Pt), _p(Wn2T), E, V,
+          _p(g_bw), _p(g_pre1), _p(g_pre2), _stream())
+    return g_bw, g_pre1, g_pre2
+
+
+def lcao_weight_bwd_fused(g_bw, B, ft, WbT, W3T, want_g_ft=False):
+    """(g_B, g_tbw, g_ft|None): basis_weight^T, the normalised combine and f_three^T differentiated in one kernel."""
+    g_bw, B, ft, WbT, W3T = _f32(g_bw), _f32(B), _f32(ft), _f32(WbT), _f32(W3T)
+    E, V = B.shape
+    g_B, g_tbw = torch.empty_like(B), torch.empty_like(B)
+    g_ft = torch.empty_like(B) if want_g_ft else None
+    _call("lcao_lcao_weight_bwd_fused", _p(g_bw), _p(B), _p(ft), _p(WbT), _p(W3T), E, V, _p(g_B), _p(g_tbw), _p(g_ft),
+          _stream())
+    return g_B, g_tbw, g_ft
+
+
 def act_bwd(g, pre, act):
     g, pre = _f32(g), _f32(pre)
     out = torch.empty_like(g)
