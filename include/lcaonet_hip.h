@@ -220,6 +220,9 @@ int lcao_message_bwd(const float* g_agg, const int32_t* src_p, const float* bw, 
                      float* g_bw, float* g_pre2, void* stream);
 int lcao_combine_bwd(const float* g_lw, const float* B, const float* ft, int64_t n_edges, int V, float* g_B, float* g_ft,
                      void* stream);
+/* add_valence form: ft (E,2V) = [ft_a | ft_b], u = B (1+ft_a) + Bv (1+ft_b);  g_ft (E,2V) = [g_u B | g_u Bv] */
+int lcao_combine_bwd_valence(const float* g_lw, const float* B, const float* Bv, const float* ft, int64_t n_edges, int V,
+                             float* g_B, float* g_Bv, float* g_ft, void* stream);
 /* Fused MFMA forms of the two-body reverse sweep (V in {32, 64, 128}; what torch.autograd does for lcaonet.py:192-213).
  * lcao_message_bwd_fused = lcao_message_bwd + Dense^T(f_node.2) + SiLU'(pre1), pre1 = Ps[src_p] + Pt[dst_p] recomputed:
  *   g_bw = g_agg[src_p] SiLU(pre2);  g_pre2 = g_agg[src_p] bw SiLU'(pre2);  g_pre1 = (g_pre2 Wn2) SiLU'(pre1)

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lcao_edge_node_message": [P, P, P, P, P, P, P, L, I, P, P],
     "lcao_edge_lcao_weight_saving": [P, P, P, P, L, I, P, P, P],
     "lcao_edge_node_message_saving": [P, P, P, P, P, P, P, L, I, P, P, P],
+    "lcao_combine_bwd_valence": [P, P, P, P, L, I, P, P, P, P],
     "lcao_message_bwd_fused": [P, P, P, P, P, P, P, P, L, I, P, P, P, P],
     "lcao_lcao_weight_bwd_fused": [P, P, P, P, P, L, I, P, P, P, P],
     "lcao_edge_lcao_weight_bf16x3": [P, P, P, P, L, I, P, P],

@@ -146,6 +146,73 @@ extern "C" int lcao_combine_bwd(const float* g_lw, const float* B, const float* 
   return lcao_launch_status();
 }
 
+// add_valence form (lcaonet.py:195-203): u = B (1 + ft_a) + Bv (1 + ft_b), ft = [ft_a | ft_b] (E, 2V):
+//   g_B = g_u (1 + ft_a);  g_Bv = g_u (1 + ft_b);  g_ft = [g_u B | g_u Bv]
+template <int R>
+__global__ void k_combine_bwd_valence(const float* __restrict__ g_lw, const float* __restrict__ B,
+                                      const float* __restrict__ Bv, const float* __restrict__ ft, int64_t E, int V,
+                                      float* __restrict__ g_B, float* __restrict__ g_Bv, float* __restrict__ g_ft) {
+  int lane = threadIdx.x & 63;
+  int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; p < E; p += nwave) {
+    float u[R], gl[R], b[R], bv[R], fa[R], fb[R];
+    float n2 = 0.f, dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int ch = lane + 64 * r;
+      b[r] = bv[r] = fa[r] = fb[r] = u[r] = gl[r] = 0.f;
+      if (ch < V) {
+        b[r] = B[p * V + ch];
+        bv[r] = Bv[p * V + ch];
+        fa[r] = ft[p * 2 * V + ch];
+        fb[r] = ft[p * 2 * V + V + ch];
+        u[r] = (b[r] + b[r] * fa[r]) + (bv[r] + bv[r] * fb[r]);
+        gl[r] = g_lw[p * V + ch];
+      }
+      n2 += u[r] * u[r];
+      dot += u[r] * gl[r];
+    }
+    n2 = lcao_wave_sum(n2);
+    dot = lcao_wave_sum(dot);
+    const float nrm = sqrtf(n2);
+    const bool live = nrm > 1e-12f;
+    const float inv = live ? 1.0f / nrm : 1e12f;
+    const float proj = live ? dot * inv * inv : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int ch = lane + 64 * r;
+      if (ch < V) {
+        const float gu = inv * (gl[r] - u[r] * proj);
+        g_B[p * V + ch] = gu * (1.0f + fa[r]);
+        g_Bv[p * V + ch] = gu * (1.0f + fb[r]);
+        g_ft[p * 2 * V + ch] = gu * b[r];
+        g_ft[p * 2 * V + V + ch] = gu * bv[r];
+      }
+    }
+  }
+}
+
+extern "C" int lcao_combine_bwd_valence(const float* g_lw, const float* B, const float* Bv, const float* ft,
+                                        int64_t n_edges, int V, float* g_B, float* g_Bv, float* g_ft, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(g_lw); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(Bv); LCAO_CHECK_PTR(ft); LCAO_CHECK_PTR(g_B);
+  LCAO_CHECK_PTR(g_Bv); LCAO_CHECK_PTR(g_ft);
+  dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  int R = (V + 63) / 64;
+#define CBV(RR) hipLaunchKernelGGL(k_combine_bwd_valence<RR>, grid, block, 0, st, g_lw, B, Bv, ft, n_edges, V, g_B, g_Bv, g_ft)
+  if (R == 1) CBV(1);
+  else if (R == 2) CBV(2);
+  else if (R <= 4) CBV(4);
+  else CBV(8);
+#undef CBV
+  return lcao_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // e2 backward — three-body term  tbw[p] = sum_{q in In(s), q != p} sum_l w_pql Ag[q,l,:],
 //   w_pql = Y_l(c) * inv,  c = u_p . u_q,  inv = 1 / max(sqrt(m), eps),  m = Y^T G_q Y   (G upper-triangular, 10 floats)

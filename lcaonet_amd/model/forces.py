@@ -7,7 +7,8 @@ hand-written reverse sweep runs on the HIP kernels of csrc/lcao_backward.hip: de
 `lcao_dense` on transposed weights, everything else by small vector-Jacobian kernels.  Only activation gradients are
 propagated (inference); parameter gradients — training — are the remaining part of SURVEY.md §8f-3.
 
-Restrictions (each raises NotImplementedError): eval mode, SiLU activations, add_valence=False, built-in cutoff / basis.
+Restrictions (each raises NotImplementedError): eval mode, SiLU activations, built-in cutoff / basis.
+add_valence=True runs the unfused two-body kernels and three pair-table passes per layer.
 """
 from __future__ import annotations
 
@@ -32,7 +33,7 @@ def _in_sum(rows: Tensor, ctx, n_nodes: int) -> Tensor:
 
 
 @torch.no_grad()
-def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim):
+def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, mask_pair=None):
     """One interaction layer in pair-table form; returns (x_new, saved tensors for the reverse sweep)."""
     V = layer.emb_size_conv
     wn, bn_ = layer.node_weight.weight.detach(), layer.node_weight.bias.detach()
@@ -44,9 +45,18 @@ def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim)
     Pt = ops.dense(xs, w1[:, V:].contiguous())
     Tf = ops.dense(ops.dense(Tf_in, layer.f_coeffs[0].weight.detach(), None, ACT), layer.f_coeffs[2].weight.detach(),
                    None, ACT)
-    Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
+    pc = lambda T: ops.pair_contract(T, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
+    Bv = None
+    if layer.add_valence:
+        from .lcaonet import split_valence_table
+        Tc, Tv = split_valence_table(Tf, mask_pair, V)
+        Tf = (Tc + Tv, Tc, Tv)
+        Ag, gram, _ = pc(Tf[0])
+        B, Bv = pc(Tc)[2], pc(Tv)[2]
+    else:
+        Ag, gram, B = pc(Tf)
     tbw = ops.triplet_gemm(Ag, gram, uvec_p, ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
-    if V in ops.FUSED_WIDTHS:
+    if V in ops.FUSED_WIDTHS and not layer.add_valence:
         # the forward's fused two-body kernels, keeping ft and pre2; pre1 = Ps[s] + Pt[t] is recomputed in the sweep
         bw, ft = ops.edge_lcao_weight(tbw, B, layer.f_three[0].weight.detach(), layer.basis_weight.weight.detach(),
                                       save=True)
@@ -56,14 +66,14 @@ def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim)
         pre1 = None
     else:
         ft = ops.dense(tbw, layer.f_three[0].weight.detach())
-        lw = ops.edge_combine(ft, B, None)
+        lw = ops.edge_combine(ft, B, Bv)
         bw = ops.dense(lw, layer.basis_weight.weight.detach())
         pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
         h1 = torch.nn.functional.silu(pre1)
         pre2 = ops.dense(h1, layer.f_node[2].weight.detach(), layer.f_node[2].bias.detach())
         agg = ops.segment_sum(bw, ctx.out_ptr, torch.nn.functional.silu(pre2))
     x_new = ops.dense(agg, layer.out_weight.weight.detach(), None, ops.ACT_NONE, x)
-    saved = dict(xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, ft=ft, bw=bw, pre1=pre1, pre2=pre2, Ps=Ps, Pt=Pt)
+    saved = dict(xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, Bv=Bv, ft=ft, bw=bw, pre1=pre1, pre2=pre2, Ps=Ps, Pt=Pt)
     return x_new, saved
 
 
@@ -76,7 +86,8 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     g_agg = ops.dense(g_xnew, _t(layer.out_weight.weight))
     # msg = bw * silu(pre2), agg = segment sum
     # bw = lw Wb^T ; lw = normalize(B (1 + ft)) ; ft = tbw W3^T
-    if V in ops.FUSED_WIDTHS:
+    g_Bv = None
+    if V in ops.FUSED_WIDTHS and not layer.add_valence:
         g_bw, g_pre1, _ = ops.message_bwd_fused(g_agg, ctx.src_p, ctx.dst_p, sv["bw"], sv["pre2"], sv["Ps"], sv["Pt"],
                                                 _t(layer.f_node[2].weight))
         g_B, g_tbw, _ = ops.lcao_weight_bwd_fused(g_bw, sv["B"], sv["ft"], _t(layer.basis_weight.weight),
@@ -86,7 +97,10 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
         g_h1 = ops.dense(g_pre2, _t(layer.f_node[2].weight))
         g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
         g_lw = ops.dense(g_bw, _t(layer.basis_weight.weight))
-        g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
+        if layer.add_valence:
+            g_B, g_Bv, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"], sv["Bv"])
+        else:
+            g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
         g_tbw = ops.dense(g_ft, _t(layer.f_three[0].weight))
     g_Ps = ops.segment_sum(g_pre1, ctx.out_ptr)          # pre1 = Ps[src] + Pt[dst]
     g_Pt = _in_sum(g_pre1, ctx, N)
@@ -96,8 +110,17 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     g_u_p += g_uq
     g_u_p += g_up
     # pair-table contraction: A from rb and Tf; Ag = A gate; B; gram
-    g_gate_part = ops.pair_contract_bwd(sv["Tf"], rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"], g_Ag, g_B,
-                                        g_gram, E, n_l, zdim, g_rb)
+    pcb = lambda T, gA, gB, gG: ops.pair_contract_bwd(T, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"], gA, gB,
+                                                      gG, E, n_l, zdim, g_rb)
+    if layer.add_valence:
+        # A (three-body) comes from Tc + Tv, B from Tc, Bv from Tv: three passes, each adding its part of dE/drb
+        Te, Tc, Tv = sv["Tf"]
+        zA, zB, zG = torch.zeros_like(g_Ag), torch.zeros_like(g_B), torch.zeros_like(g_gram)
+        g_gate_part = pcb(Te, g_Ag, zB, g_gram)
+        pcb(Tc, zA, g_B, zG)
+        pcb(Tv, zA, g_Bv, zG)
+    else:
+        g_gate_part = pcb(sv["Tf"], g_Ag, g_B, g_gram)
     g_gate = ops.segment_sum(g_gate_part, ctx.out_ptr)
     g_xk = ops.act_bwd(g_gate, sv["xk"], ops.ACT_SIGMOID)
     # node level: Ps = xs Wa^T + b, Pt = xs Wb^T ; [xs | xk] = x Wnw^T + b
@@ -113,8 +136,6 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
 def _check_supported(model):
     if model.training:
         raise NotImplementedError("autograd forces: eval mode only (BatchNorm batch statistics are not differentiated)")
-    if model.add_valence:
-        raise NotImplementedError("autograd forces with add_valence=True are not built yet")
     acts = [model.int_layers[0].f_coeffs[1], model.int_layers[0].f_node[1], model.out_layer.out_lin[1]]
     if not all(type(a) is nn.SiLU for a in acts):
         raise NotImplementedError("autograd forces are built for the default SiLU activation")
@@ -143,9 +164,10 @@ def forward_with_autograd_forces(model, graph):
     x, cst_pair, zdim = model.emb_layer.forward_pair_table(z)
     l_of_d, n_l = model.shbf.l_of_d, model.n_l
 
+    mask_pair = model.pair_valence_mask(zdim) if model.add_valence else None
     saved, x_in = [], x
     for layer in model.int_layers:
-        x_in, sv = layer_forward_saving(layer, x_in, cst_pair, rb, uvec_p, ctx, l_of_d, n_l, z, zdim)
+        x_in, sv = layer_forward_saving(layer, x_in, cst_pair, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, mask_pair)
         saved.append(sv)
     xL = x_in
 

@@ -158,6 +158,11 @@ class LCAOEmbedding(nn.Module):
         return x, cst_pair, zd
 
 
+def split_valence_table(Tf: Tensor, mask_pair: Tensor, V: int) -> tuple[Tensor, Tensor]:
+    """f_coeffs(pair table) (P, D, 2V) -> (Tc, Tv) = (plain half, valence half masked by the neighbour species)."""
+    return Tf[..., :V].contiguous(), (Tf[..., V:] * mask_pair.unsqueeze(-1)).contiguous()
+
+
 class LCAOInteraction(nn.Module):
     """One LCAOConv message-passing layer (reference lcaonet.py:77-216); same parameters and names."""
 
@@ -240,10 +245,18 @@ class LCAOInteraction(nn.Module):
         if pair is not None:
             # cst here is the ((max_z+1)^2, D, C) species-pair table: f_coeffs runs on ~1.4 k x D rows, and the
             # per-edge work is a contraction of the cache-resident table with rb (no 2*D*(C*V+V*V) flop per edge)
-            z, zdim = pair
+            z, zdim = pair[0], pair[1]
             Tf = run_mlp(self.f_coeffs, cst)
-            Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
-            Bv = None
+            pc = lambda T: ops.pair_contract(T, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, gate, n_l, zdim)
+            if self.add_valence:
+                # lcaonet.py:174-183,195-203 on the table: the valence half is masked by the neighbour species, the
+                # three-body term sees the sum of both halves, the two-body term keeps them apart (B, Bv)
+                Tc, Tv = split_valence_table(Tf, pair[2], V)
+                Ag, gram, _ = pc(Tc + Tv)
+                B, Bv = pc(Tc)[2], pc(Tv)[2]
+            else:
+                Ag, gram, B = pc(Tf)
+                Bv = None
             tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
         elif fused and precision == "bf16x3" and not self.add_valence:
             # BASELINE config 3: bf16 MFMA on the per-edge coefficient GEMMs, operands split into two bf16 terms
@@ -497,6 +510,11 @@ class LCAONet(BaseMPNN):
         return self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision)
 
     @torch.no_grad()
+    def pair_valence_mask(self, zdim: int) -> Tensor:
+        """(zdim^2, D) 0/1: row z_s*zdim + z_t = valence orbitals of the NEIGHBOUR species z_t (embed.py:102-133 through
+        ValenceMask.forward(z, idx_t))."""
+        return self.valence_mask.valence[:zdim].to(torch.float32).repeat(zdim, 1).contiguous()
+
     def _forward_inference(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
                            trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
                            precision: str = "fp32"):
@@ -524,10 +542,10 @@ class LCAONet(BaseMPNN):
         if cst_mode == "pair":
             # cst_mode="pair": species-pair table instead of the per-edge (E, D, C) tensor.  Same
             # outputs; valid when cst comes from this model's own embedding in eval mode.
-            if self.training or self.add_valence:
-                raise NotImplementedError("cst_mode='pair' needs eval mode and add_valence=False")
+            if self.training:
+                raise NotImplementedError("cst_mode='pair' needs eval mode (train mode: differentiable=True)")
             x, cst, zdim = self.emb_layer.forward_pair_table(z)
-            pair = (z, zdim)
+            pair = (z, zdim, self.pair_valence_mask(zdim) if self.add_valence else None)
         elif cst_mode != "edge":
             raise ValueError(f"cst_mode={cst_mode!r}: expected 'edge' or 'pair'")
         elif self.training:

@@ -10,7 +10,7 @@ Structure (all of it is exact, summation order aside):
     pair-table HIP pipeline of model/lcaonet.py; its backward is the reverse sweep of model/forces.py extended with
     weight gradients.  Weight-gradient products G^T X are plain GEMMs and go through the vendor library (torch.mm).
   * The output heads (N-level MLPs) and the per-graph reduction are torch ops under autograd.
-Not built: double backward (training on autograd forces, create_graph=True) and add_valence.
+Not built: double backward (training on autograd forces, create_graph=True).
 """
 from __future__ import annotations
 
@@ -149,30 +149,39 @@ class LCAOStackFn(torch.autograd.Function):
         saved = []
         for i in range(n_layers):
             Wnw, bnw, W3, Wb, Wn1, bn1, Wn2, bn2, Wout = [p.detach() for p in params[i * 9:(i + 1) * 9]]
-            V = W3.shape[0]
+            V = Wb.shape[0]
             xs = ops.dense(x, Wnw[:V], bnw[:V])
             xk = ops.dense(x, Wnw[V:], bnw[V:])
             gate = torch.sigmoid(xk)
             Ps = ops.dense(xs, Wn1[:, :V].contiguous(), bn1)
             Pt = ops.dense(xs, Wn1[:, V:].contiguous())
             Tf = Tfs[i].detach().contiguous()
-            Ag, gram, B = ops.pair_contract(Tf, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, gate, geom.n_l, geom.zd)
+            pc = lambda T: ops.pair_contract(T, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, gate, geom.n_l, geom.zd)
+            valence = Tf.shape[-1] == 2 * V     # add_valence: [plain half | masked valence half] (lcaonet.py:174-183)
+            Bv = None
+            if valence:
+                Tc, Tv = Tf[..., :V].contiguous(), Tf[..., V:].contiguous()
+                Tf = (Tc + Tv, Tc, Tv)
+                Ag, gram, _ = pc(Tf[0])
+                B, Bv = pc(Tc)[2], pc(Tv)[2]
+            else:
+                Ag, gram, B = pc(Tf)
             tbw = ops.triplet_gemm(Ag, gram, geom.uvec_p, ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
-            if V in ops.FUSED_WIDTHS:
+            if V in ops.FUSED_WIDTHS and not valence:
                 bw, ft = ops.edge_lcao_weight(tbw, B, W3, Wb, save=True)
                 msg, pre2 = ops.edge_node_message(bw, Ps, Pt, ctx.src_p, ctx.dst_p, Wn2, bn2, save=True)
                 agg = ops.segment_sum(msg, ctx.out_ptr)
                 pre1 = None
             else:
                 ft = ops.dense(tbw, W3)
-                lw = ops.edge_combine(ft, B, None)
+                lw = ops.edge_combine(ft, B, Bv)
                 bw = ops.dense(lw, Wb)
                 pre1 = ops.pair_pre(Ps, Pt, ctx.src_p, ctx.dst_p)
                 h1 = F.silu(pre1)
                 pre2 = ops.dense(h1, Wn2, bn2)
                 agg = ops.segment_sum(bw, ctx.out_ptr, F.silu(pre2))
             x_new = ops.dense(agg, Wout, None, ops.ACT_NONE, x)
-            saved.append(dict(x=x, xs=xs, xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, tbw=tbw, ft=ft, bw=bw,
+            saved.append(dict(x=x, xs=xs, xk=xk, gate=gate, Tf=Tf, Ag=Ag, gram=gram, B=B, Bv=Bv, tbw=tbw, ft=ft, bw=bw,
                               pre1=pre1, pre2=pre2, agg=agg, Ps=Ps, Pt=Pt))
             x = x_new
         fctx.geom, fctx.n_layers, fctx.saved = geom, n_layers, saved
@@ -197,12 +206,13 @@ class LCAOStackFn(torch.autograd.Function):
         for i in reversed(range(L)):
             Wnw, bnw, W3, Wb, Wn1, bn1, Wn2, bn2, Wout = params[i * 9:(i + 1) * 9]
             sv = saved[i]
-            V = W3.shape[0]
+            V = Wb.shape[0]
+            valence = sv["Bv"] is not None
             gp = g_params
             # x' = x + agg Wout^T
             gp[i * 9 + 8] = _mm_t(g_x, sv["agg"])
             g_agg = ops.dense(g_x, Wout.t().contiguous())
-            fused = V in ops.FUSED_WIDTHS
+            fused = V in ops.FUSED_WIDTHS and not valence
             if fused:
                 g_bw, g_pre1, g_pre2 = ops.message_bwd_fused(g_agg, ctx.src_p, ctx.dst_p, sv["bw"], sv["pre2"], sv["Ps"],
                                                              sv["Pt"], Wn2.t().contiguous(), want_g_pre2=True)
@@ -217,7 +227,7 @@ class LCAOStackFn(torch.autograd.Function):
             del h1, g_pre2
             g_Ps = ops.segment_sum(g_pre1, ctx.out_ptr)
             g_Pt = ops.segment_sum(ops.gather_rows(g_pre1, ctx.in_pos), ctx.in_ptr)
-            lw = ops.edge_combine(sv["ft"], sv["B"], None)
+            lw = ops.edge_combine(sv["ft"], sv["B"], sv["Bv"])
             gp[i * 9 + 3] = _mm_t(g_bw, lw)
             del lw
             if fused:
@@ -225,19 +235,30 @@ class LCAOStackFn(torch.autograd.Function):
                                                              W3.t().contiguous(), want_g_ft=True)
             else:
                 g_lw = ops.dense(g_bw, Wb.t().contiguous())
-                g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
+                if valence:
+                    g_B, g_Bv, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"], sv["Bv"])
+                else:
+                    g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
                 g_tbw = ops.dense(g_ft, W3.t().contiguous())
             gp[i * 9 + 2] = _mm_t(g_ft, sv["tbw"])
             if V not in ops.FUSED_WIDTHS and n_dense is None:
                 n_dense = int(prod.sum().item())
             g_Ag, g_gram, _, _ = ops.triplet_bwd(g_tbw, sv["Ag"], sv["gram"], geom.uvec_p, ctx.src_p, ctx.dst_p, ctx.in_ptr,
                                                  ctx.in_pos, ctx.out_ptr, tbase, n_dense or 1, E, N)
-            g_gate_part, g_A = ops.pair_contract_bwd(sv["Tf"], rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p,
-                                                     sv["gate"], g_Ag, g_B, g_gram, E, geom.n_l, geom.zd, g_rb_sink,
-                                                     want_gA=True)
-            partial = ops.pair_table_grad(g_A, rb, ctx.order, geom.l_of_d, geom.perm_pair, geom.chunk_ptr)
             D = rb.shape[1]
-            g_Tf[i] = ops.segment_sum(partial.reshape(partial.shape[0], D * V), geom.pair_cptr).reshape(-1, D, V)
+
+            def table_grad(g_A):
+                partial = ops.pair_table_grad(g_A, rb, ctx.order, geom.l_of_d, geom.perm_pair, geom.chunk_ptr)
+                return ops.segment_sum(partial.reshape(partial.shape[0], D * V), geom.pair_cptr).reshape(-1, D, V)
+
+            Te = sv["Tf"][0] if valence else sv["Tf"]
+            g_gate_part, g_A = ops.pair_contract_bwd(Te, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"],
+                                                     g_Ag, torch.zeros_like(g_B) if valence else g_B, g_gram, E, geom.n_l,
+                                                     geom.zd, g_rb_sink, want_gA=True)
+            if valence:   # A sees Tc + Tv, B sees Tc, Bv sees Tv: the shared part of g_A plus each half's own g_B
+                g_Tf[i] = torch.cat([table_grad(g_A + g_B.unsqueeze(1)), table_grad(g_A + g_Bv.unsqueeze(1))], dim=-1)
+            else:
+                g_Tf[i] = table_grad(g_A)
             g_gate = ops.segment_sum(g_gate_part, ctx.out_ptr)
             g_xk = ops.act_bwd(g_gate, sv["xk"], ops.ACT_SIGMOID)
             xs = sv["xs"]
@@ -255,8 +276,6 @@ class LCAOStackFn(torch.autograd.Function):
 
 def forward_differentiable(model, graph):
     """LCAONet.forward with an autograd graph to every parameter (training).  Same outputs as the inference path."""
-    if model.add_valence:
-        raise NotImplementedError("training with add_valence=True is not built yet")
     if model.regress_forces and not model.direct_forces:
         raise NotImplementedError("training on autograd forces needs a double backward, which is not built yet")
     for layer in model.int_layers:
@@ -273,6 +292,10 @@ def forward_differentiable(model, graph):
         geom.pair_lists(pair, zd)
     L = model.n_interaction
     Tfs = [_mlp(layer.f_coeffs, cst_pair) for layer in model.int_layers]
+    if model.add_valence:   # mask the valence half by the neighbour species (differentiable: plain torch on the table)
+        V = model.emb_size_conv
+        mp = model.pair_valence_mask(zd).unsqueeze(-1)
+        Tfs = [torch.cat([T[..., :V], T[..., V:] * mp], dim=-1) for T in Tfs]
     params = []
     for layer in model.int_layers:
         sd = dict(layer.named_parameters())

@@ -416,9 +416,15 @@ def message_bwd(g_agg, src_p, bw, pre2):
     return g_bw, g_pre2
 
 
-def combine_bwd(g_lw, B, ft):
+def combine_bwd(g_lw, B, ft, Bv=None):
+    """(g_B, g_ft), or (g_B, g_Bv, g_ft) with the valence term Bv and ft (E, 2V)."""
     g_lw, B, ft = _f32(g_lw), _f32(B), _f32(ft)
     E, V = B.shape
+    if Bv is not None:
+        Bv = _f32(Bv)
+        g_B, g_Bv, g_ft = torch.empty_like(B), torch.empty_like(B), torch.empty_like(ft)
+        _call("lcao_combine_bwd_valence", _p(g_lw), _p(B), _p(Bv), _p(ft), E, V, _p(g_B), _p(g_Bv), _p(g_ft), _stream())
+        return g_B, g_Bv, g_ft
     g_B, g_ft = torch.empty_like(B), torch.empty_like(B)
     _call("lcao_combine_bwd", _p(g_lw), _p(B), _p(ft), E, V, _p(g_B), _p(g_ft), _stream())
     return g_B, g_ft

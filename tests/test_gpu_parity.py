@@ -369,11 +369,14 @@ def test_sharded_forward_hip_matches_unsharded(dev, world, cells):
     assert relerr(total, full) <= 2e-6
 
 
-@pytest.mark.parametrize("width,heads", [(128, 64), (64, 64), (32, 16), (48, 16)])
-def test_pair_table_mode_vs_oracle_and_edge_mode(dev, width, heads):
-    """cst_mode='pair' (SURVEY.md §8f-2): identical outputs from the species-pair table."""
+@pytest.mark.parametrize("width,heads,valence", [(128, 64, False), (64, 64, False), (32, 16, False), (48, 16, False),
+                                                  (128, 32, True), (48, 16, True)])
+def test_pair_table_mode_vs_oracle_and_edge_mode(dev, width, heads, valence):
+    """cst_mode='pair' (SURVEY.md §8f-2): identical outputs from the species-pair table, with and without the
+    add_valence halves."""
     from lcaonet_amd.data.synthetic import random_periodic_cells
-    kw = dict(emb_size=heads, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0, max_z=36)
+    kw = dict(emb_size=heads, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0, max_z=36,
+              add_valence=valence)
     m, sd = _random_model(dev, 300 + width, **kw)
     g = random_periodic_cells(3, 14, 6.2, 0.99 * 5.0, seed=width + 1)
     want, wtr = _oracle_run(sd, kw, g.to_dict())
@@ -537,7 +540,7 @@ def test_cfg5_shape_molecules_vs_oracle(dev):
     assert relerr(got_p, want) <= TOL and relerr(force_p, wforce) <= TOL
 
 
-@pytest.mark.parametrize("case", ["cells128", "cells48_out2_mean", "molecules_bessel"])
+@pytest.mark.parametrize("case", ["cells128", "cells48_out2_mean", "molecules_bessel", "cells64_valence"])
 def test_autograd_forces_vs_oracle(dev, case):
     """Hand-written reverse sweep (model/forces.py + csrc/lcao_backward.hip) against torch.autograd through the oracle,
     fp32 and fp64; also a finite-difference spot check of one coordinate."""
@@ -545,6 +548,9 @@ def test_autograd_forces_vs_oracle(dev, case):
     if case == "cells128":
         kw = dict(emb_size=64, emb_size_coeff=128, emb_size_conv=128, n_interaction=2, cutoff=5.0)
         g = random_periodic_cells(3, 12, 6.0, 0.99 * 5.0, seed=11)
+    elif case == "cells64_valence":
+        kw = dict(emb_size=32, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=5.0, add_valence=True)
+        g = random_periodic_cells(3, 12, 6.0, 0.99 * 5.0, seed=13)
     elif case == "cells48_out2_mean":
         kw = dict(emb_size=32, emb_size_coeff=24, emb_size_conv=48, n_interaction=3, cutoff=4.0, out_size=2,
                   is_extensive=False, cutoff_net="polynomial", max_z=84)
@@ -579,12 +585,14 @@ def _oracle_param_grads(sd, kw, graph_cpu, proj, training):
     return out.detach(), {k: v.grad for k, v in sdg.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
 
 
-@pytest.mark.parametrize("width,training", [(128, True), (64, False), (48, True)])
-def test_parameter_gradients_vs_oracle_autograd(dev, width, training):
+@pytest.mark.parametrize("width,training,valence", [(128, True, False), (64, False, False), (48, True, False),
+                                                    (64, True, True)])
+def test_parameter_gradients_vs_oracle_autograd(dev, width, training, valence):
     """Training backward (model/train.py): every parameter's gradient against torch.autograd through the fp64 oracle,
     in train mode (BatchNorm batch statistics as count-weighted species / pair statistics) and in eval mode."""
     from lcaonet_amd.data.synthetic import random_periodic_cells
-    kw = dict(emb_size=32, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0, out_size=2)
+    kw = dict(emb_size=32, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0, out_size=2,
+              add_valence=valence)
     m, sd = _random_model(dev, 400 + width, **kw)
     m.train(training)
     g = random_periodic_cells(3, 12, 6.0, 0.99 * 5.0, seed=21)
@@ -633,7 +641,7 @@ def test_training_reduces_loss(dev, golden_loader):
         loss = torch.nn.functional.l1_loss(m(g), target)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
 
 
