@@ -220,6 +220,12 @@ int lcao_message_bwd(const float* g_agg, const int32_t* src_p, const float* bw, 
                      float* g_bw, float* g_pre2, void* stream);
 int lcao_combine_bwd(const float* g_lw, const float* B, const float* ft, int64_t n_edges, int V, float* g_B, float* g_ft,
                      void* stream);
+/* Weight gradient of a Dense layer applied to n_rows rows (training, lcaonet.py loss.backward()):
+ *   dW (M, K) = G^T X,   G (n_rows, M) = dE/d(output rows),  X (n_rows, K) = input rows;  M, K multiples of 64.
+ * fp32 MFMA, deterministic two-stage sum; workspace of lcao_wgrad_workspace_bytes(n_rows, M, K) bytes. */
+size_t lcao_wgrad_workspace_bytes(int64_t n_rows, int M, int K);
+int lcao_wgrad(const float* G, const float* X, int64_t n_rows, int M, int K, float* dW, void* workspace, size_t ws_bytes,
+               void* stream);
 /* add_valence form: ft (E,2V) = [ft_a | ft_b], u = B (1+ft_a) + Bv (1+ft_b);  g_ft (E,2V) = [g_u B | g_u Bv] */
 int lcao_combine_bwd_valence(const float* g_lw, const float* B, const float* Bv, const float* ft, int64_t n_edges, int V,
                              float* g_B, float* g_Bv, float* g_ft, void* stream);

@@ -44,6 +44,8 @@ SIGNATURES = {
     "lcao_edge_node_message": [P, P, P, P, P, P, P, L, I, P, P],
     "lcao_edge_lcao_weight_saving": [P, P, P, P, L, I, P, P, P],
     "lcao_edge_node_message_saving": [P, P, P, P, P, P, P, L, I, P, P, P],
+    "lcao_wgrad": [P, P, L, I, I, P, P, c_size_t, P],
+    "lcao_wgrad_workspace_bytes": [L, I, I],
     "lcao_combine_bwd_valence": [P, P, P, P, L, I, P, P, P, P],
     "lcao_message_bwd_fused": [P, P, P, P, P, P, P, P, L, I, P, P, P, P],
     "lcao_lcao_weight_bwd_fused": [P, P, P, P, P, L, I, P, P, P, P],
@@ -62,7 +64,7 @@ SIGNATURES = {
     "lcao_debug_set_clock_probe": [P],
 }
 _RESTYPES = {"lcao_error_string": c_char_p, "lcao_lds_bytes_coeff_mlp": c_size_t,
-             "lcao_build_csr_workspace_bytes": c_size_t, "lcao_nl_workspace_bytes": c_size_t, "lcao_debug_set_clock_probe": None}
+             "lcao_build_csr_workspace_bytes": c_size_t, "lcao_nl_workspace_bytes": c_size_t, "lcao_wgrad_workspace_bytes": c_size_t, "lcao_debug_set_clock_probe": None}
 
 _lib = None
 

@@ -1417,6 +1417,116 @@ extern "C" int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const 
 }
 
 // ===================================================================================================
+// lcao_wgrad — weight gradient of a Dense layer applied to E rows:  dW (M x K) = G^T X,  G (E x M), X (E x K).
+// A reduction over ~10^6 rows with a 128 x 128 result: every wave owns one 64 x 64 block of dW for one chunk of rows,
+// 16 MFMA accumulators, the 4 rows of a k-step on the four lane quarters.  A lane loads 16 B of G and 16 B of X per step:
+// its four floats feed four DIFFERENT feature tiles (tile j <-> features 4i + j, i = lane & 15), a permuted tiling that
+// the epilogue undoes — so operands come straight from global memory as float4, no LDS, no transposition.  Chunk
+// partials are summed in a fixed order by a second kernel (deterministic, no atomics).
+// ===================================================================================================
+#define LCAO_WGRAD_CHUNKS 512
+
+__global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__ G, const float* __restrict__ X,
+                                                       int64_t E, int M, int K, int n_chunks,
+                                                       float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int kb = K >> 6, n_blocks = (M >> 6) * kb;
+  const int block = blockIdx.y * 4 + wave;
+  if (block >= n_blocks) return;
+  const int bm = block / kb, bk = block - bm * kb;
+  const int64_t rows = ((E + n_chunks - 1) / n_chunks + 3) & ~int64_t(3);
+  const int64_t r0 = blockIdx.x * rows, r1 = min(r0 + rows, E);
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const float* gp = G + 64 * bm + 4 * i;
+  const float* xp = X + 64 * bk + 4 * i;
+  const f32x4v zero = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const int n_steps = (int)((r1 - r0 + 3) >> 2);
+  for (int s0 = 0; s0 < n_steps; s0 += 4) {   // 4 k-steps (16 rows) per iteration: 8 independent 16-B loads in flight
+    f32x4v g[4], x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t e = r0 + 4 * (int64_t)(s0 + u) + kq;
+      const bool ok = e < r1;
+      g[u] = ok ? *(const f32x4v*)(gp + e * M) : zero;
+      x[u] = ok ? *(const f32x4v*)(xp + e * K) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = MFMA16(g[u][a], x[u][b], acc[a][b]);
+  }
+  // acc[a][b] reg r, lane (i, kq): row index 4*kq + r of feature tile a  <->  m = 64 bm + 4 (4 kq + r) + a;  column i of
+  // tile b <-> k = 64 bk + 4 i + b.   The four b's of a lane are 16 contiguous bytes.
+  float* out = partial + (int64_t)blockIdx.x * M * K;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 64 * bm + 4 * (4 * kq + r) + a;
+      const f32x4v v = f32x4v{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+      *(f32x4v*)(out + (int64_t)m * K + 64 * bk + 4 * i) = v;
+    }
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int64_t mk, float* __restrict__ dW) {
+  const int64_t j = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
+  if (j >= mk) return;
+  f32x4v s0 = f32x4v{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int c = 0;
+  for (; c + 4 <= n_chunks; c += 4) {   // fixed association: four interleaved running sums, then (s0+s1)+(s2+s3)
+    s0 += *(const f32x4v*)(partial + (int64_t)c * mk + j);
+    s1 += *(const f32x4v*)(partial + (int64_t)(c + 1) * mk + j);
+    s2 += *(const f32x4v*)(partial + (int64_t)(c + 2) * mk + j);
+    s3 += *(const f32x4v*)(partial + (int64_t)(c + 3) * mk + j);
+  }
+  for (; c < n_chunks; ++c) s0 += *(const f32x4v*)(partial + (int64_t)c * mk + j);
+  *(f32x4v*)(dW + j) = (s0 + s1) + (s2 + s3);
+}
+
+static int wgrad_chunks(int64_t E) {
+  int64_t c = (E + 255) / 256;   // at least 256 rows per chunk
+  if (c > LCAO_WGRAD_CHUNKS) c = LCAO_WGRAD_CHUNKS;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+extern "C" size_t lcao_wgrad_workspace_bytes(int64_t n_rows, int M, int K) {
+  if (n_rows <= 0 || M <= 0 || K <= 0) return 0;
+  return (size_t)wgrad_chunks(n_rows) * M * K * sizeof(float);
+}
+
+extern "C" int lcao_wgrad(const float* G, const float* X, int64_t n_rows, int M, int K, float* dW, void* workspace,
+                          size_t ws_bytes, void* stream) {
+  LCAO_CHECK_SIZE(n_rows);
+  if (M <= 0 || K <= 0) return LCAO_ERR_INVALID;
+  if (M % 64 || K % 64) return LCAO_ERR_UNSUPPORTED;
+  LCAO_CHECK_PTR(dW);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows == 0) {
+    hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * M * K, st);
+    return e == hipSuccess ? LCAO_OK : int(e);
+  }
+  LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(X); LCAO_CHECK_PTR(workspace);
+  if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) % 16) return LCAO_ERR_INVALID;
+  const int chunks = wgrad_chunks(n_rows);
+  if (ws_bytes < (size_t)chunks * M * K * sizeof(float)) return LCAO_ERR_INVALID;
+  const int n_blocks = (M / 64) * (K / 64);
+  hipLaunchKernelGGL(k_wgrad_partial, dim3(chunks, (n_blocks + 3) / 4), dim3(256), 0, st, G, X, n_rows, M, K, chunks,
+                     (float*)workspace);
+  const int64_t mk = (int64_t)M * K;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(lcao_blocks(mk / 4, 256)), dim3(256), 0, st, (const float*)workspace, chunks, mk,
+                     dW);
+  return lcao_launch_status();
+}
+
+// ===================================================================================================
 // lcao_coeff_mlp_contract_bf16x3 — BASELINE config 3 ("bf16 MFMA on the per-edge coeffs x hidden GEMM"):
 // the same fused kernel as lcao_coeff_mlp_contract with both Dense layers on v_mfma_f32_16x16x32_bf16.
 // Plain bf16 operands cost 3.6e-3 relative error on this MLP (worse than config 3's own 1e-3 bound), so every fp32

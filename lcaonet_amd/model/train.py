@@ -134,8 +134,9 @@ class _Geom:
 
 
 def _mm_t(g: Tensor, x: Tensor) -> Tensor:
-    """weight gradient of y = x W^T:  dW = g^T x  (plain GEMM through the vendor library)."""
-    return torch.mm(g.t(), x)
+    """weight gradient of y = x W^T:  dW = g^T x  (lcao_wgrad: fp32 MFMA, deterministic; widths that are not multiples
+    of 64 use the vendor GEMM)."""
+    return ops.wgrad(g, x)
 
 
 class LCAOStackFn(torch.autograd.Function):

@@ -469,6 +469,21 @@ def pair_contract_bwd(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g
     return (g_gate_part, g_A) if want_gA else g_gate_part
 
 
+def wgrad(g, x):
+    """dW = g^T x for a Dense layer applied to many rows (g (E, M), x (E, K)); the MFMA kernel needs M, K % 64 == 0,
+    other shapes go to the vendor GEMM (torch.mm)."""
+    g, x = _f32(g), _f32(x)
+    E, M = g.shape
+    K = x.shape[1]
+    if M % 64 or K % 64:
+        return torch.mm(g.t(), x)
+    dW = torch.empty(M, K, device=g.device, dtype=torch.float32)
+    nbytes = int(_lib.load().lcao_wgrad_workspace_bytes(E, M, K))
+    ws = torch.empty(max(nbytes, 16), device=g.device, dtype=torch.uint8)
+    _call("lcao_wgrad", _p(g), _p(x), E, M, K, _p(dW), _p(ws), nbytes, _stream())
+    return dW
+
+
 def pair_table_grad(g_A, rb, order, l_of_d, perm, chunk_ptr):
     g_A, rb = _f32(g_A), _f32(rb)
     E, n_l, V = g_A.shape

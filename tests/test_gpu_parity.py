@@ -626,6 +626,24 @@ def test_parameter_gradients_vs_oracle_autograd(dev, width, training, valence):
         assert int(m.emb_layer.coeff_embed.bn.num_batches_tracked) == 1
 
 
+def test_wgrad_kernel(dev):
+    """lcao_wgrad (dW = G^T X over ~E rows, fp32 MFMA, two-stage deterministic sum) against an fp64 product: row counts
+    that are not multiples of the 4-row k-step or of the chunking, every 64-multiple block shape used by training,
+    the vendor-GEMM fallback for other widths, zero rows, and bitwise run-to-run determinism."""
+    from lcaonet_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for E, M, K in ((1, 64, 64), (5, 128, 64), (1023, 128, 128), (70001, 256, 128), (300000, 128, 128), (4096, 64, 192),
+                    (777, 48, 128)):
+        g = torch.randn(E, M, generator=gen).to(dev)
+        x = torch.randn(E, K, generator=gen).to(dev)
+        want = g.double().t() @ x.double()
+        got = ops.wgrad(g, x)
+        assert got.shape == (M, K)
+        assert relerr(got, want) <= 2e-6, (E, M, K, relerr(got, want))
+        assert bool((ops.wgrad(g, x) == got).all())
+    assert float(ops.wgrad(torch.zeros(0, 64, device=dev), torch.zeros(0, 128, device=dev)).abs().max()) == 0.0
+
+
 def test_training_reduces_loss(dev, golden_loader):
     """The reference's trainability check (tests/model/test_lcaonet.py:219-243): Adam steps drive the loss down."""
     from lcaonet_amd.data.synthetic import random_periodic_cells

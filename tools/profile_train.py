@@ -30,6 +30,6 @@ with ops.profile() as prof:
     ks = prof.summary()
 tot = sum(v[1] for v in ks.values()) / 5
 print(f"training step (fwd + bwd + Adam): wall {wall:.2f} ms = {E / wall * 1e3 / 1e6:.1f} M edges/s; HIP entry points {tot:.2f} ms, "
-      f"torch (weight-grad GEMMs, table autograd, optimiser) {wall - tot:.2f} ms; loss {float(loss):.4f}")
+      f"torch (weight-grad GEMMs, table autograd, optimiser) {wall - tot:.2f} ms; loss {float(loss.detach()):.4f}")
 for k, (n, ms) in sorted(ks.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f"   {k:28s} calls/step={n/5:5.1f}  {ms/5:8.3f} ms/step  {ms/n:8.4f} ms/call")
