@@ -24,6 +24,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 //   LCAO_ABL & 1: activations replaced by identity     & 2: coefficient rows loaded once per tile, not per orbital
 //   LCAO_ABL & 4: weight fragments read once per feature-tile pair instead of once per k chunk (1/KT of the LDS reads)
 //   LCAO_ABL & 8: WITHOUT the s_setprio(1) around each layer's MFMA stream     & 16: static s_setprio(1) for waves 4-7
+//   LCAO_ABL & 32 / & 64 (k_triplet_gemm, tools/k3_ablate.py): no Y_l / norm arithmetic / one MFMA per in-edge step
 #ifndef LCAO_ABL
 #define LCAO_ABL 0
 #endif
@@ -997,6 +998,9 @@ __device__ __forceinline__ int gram_idx(int l, int l2) {  // l <= l2, row-major 
 template <int NL>
 __device__ __forceinline__ float triplet_weight(float ux, float uy, float uz, float qx, float qy, float qz,
                                                 const float (&G)[10], int quarter, bool ok) {
+#if LCAO_ABL & 32
+  return ok ? (ux * qx + G[0] * (float)quarter) : 0.f;   // diagnostic: no Y_l / norm arithmetic
+#endif
   const float c = ux * qx + uy * qy + uz * qz;
   float y[4];
   y[0] = lcao_y_l0(c, 0);
@@ -1101,16 +1105,24 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
                   G[gram_idx(l, l2)] = __int_as_float(__builtin_amdgcn_readlane(r0i, 3 + gram_idx(l, l2)));
               // lcaonet.py:470 drops only the triplet whose two edges coincide (q == p); the back-triplet stays
               const float wA = triplet_weight<NL>(uax, uay, uaz, qx, qy, qz, G, quarter, vA && q0 != pA);
+#if LCAO_ABL & 64
+              acc[0][0][0] = MFMA16(F[i][0][0] + F[i][HG - 1][3] + F[i][0][1] + F[i][HG - 1][2], wA, acc[0][0][0]);  // diagnostic: 1 MFMA per step
+#else
 #pragma unroll
               for (int h = 0; h < HG; ++h)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) acc[0][h][jj] = MFMA16(F[i][h][jj], wA, acc[0][h][jj]);
+#endif
               if (two) {
                 const float wB = triplet_weight<NL>(ubx, uby, ubz, qx, qy, qz, G, quarter, vB && q0 != pB);
+#if LCAO_ABL & 64
+                acc[1][0][0] = MFMA16(F[i][0][0], wB, acc[1][0][0]);
+#else
 #pragma unroll
                 for (int h = 0; h < HG; ++h)
 #pragma unroll
                   for (int jj = 0; jj < 4; ++jj) acc[1][h][jj] = MFMA16(F[i][h][jj], wB, acc[1][h][jj]);
+#endif
               }
               // refill this slot with step j + PD
               if (j + PD < cn) {
