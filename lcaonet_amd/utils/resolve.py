@@ -46,6 +46,23 @@ def activation_resolver(query: torch.nn.Module | str = "relu", **kwargs) -> torc
     return _resolver(query, _activation_classes(), torch.nn.Module, **kwargs)
 
 
+# activation name -> nonlinearity name torch.nn.init.calculate_gain understands (resolve.py:88-98 of the reference:
+# Swish borrows the sigmoid gain, ShiftedSoftplus and anything unknown the linear one)
+_GAIN_OF = {"sigmoid": "sigmoid", "tanh": "tanh", "relu": "relu", "selu": "selu", "leakyrelu": "leaky_relu",
+            "swish": "sigmoid", "shiftedsoftplus": "linear"}
+
+
+def activation_gain_resolver(query: torch.nn.Module | str = "relu", **kwargs) -> float:
+    """Initialisation gain for an activation given by name or class (reference resolve.py:79-105)."""
+    if isinstance(query, str):
+        query = _normalize_string(query)
+    try:
+        name = _resolver(query, _activation_classes(), torch.nn.Module, False).__name__.lower()
+    except ValueError:
+        name = ""
+    return torch.nn.init.calculate_gain(_GAIN_OF.get(name, "linear"), **kwargs)
+
+
 def init_resolver(query: Callable | str = "orthogonal") -> Callable:
     if isinstance(query, str):
         query = _normalize_string(query)

@@ -71,6 +71,16 @@ def test_resolvers():
         activation_resolver("nosuchact")
 
 
+def test_activation_gain_resolver():
+    """reference utils/resolve.py:79-105"""
+    from lcaonet_amd.utils.resolve import activation_gain_resolver as gain
+    assert gain("relu") == torch.nn.init.calculate_gain("relu")
+    assert gain("Leaky_ReLU", param=0.2) == torch.nn.init.calculate_gain("leaky_relu", 0.2)
+    assert gain("swish") == gain(torch.nn.Sigmoid) == 1.0
+    assert gain("shifted-softplus") == gain("silu") == gain("no such activation") == 1.0
+    assert gain("tanh") == pytest.approx(5.0 / 3.0)
+
+
 @pytest.mark.parametrize("name", MODEL_CASES)
 def test_state_dict_is_drop_in(golden_loader, name):
     """A reference checkpoint loads with strict=True: identical parameter / buffer names and shapes."""
