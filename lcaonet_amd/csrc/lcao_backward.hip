@@ -1,6 +1,7 @@
 // lcao_backward.hip — activation-gradient (vector-Jacobian) kernels of the LCAOConv path: what
 // `-torch.autograd.grad(E, pos)` (lcaonet/model/lcaonet.py:310-317, regress_forces with direct_forces=False) needs at
-// inference.  Parameter gradients (training) are not built yet.
+// inference, and the same sweep in training (model/train.py; weight gradients: lcao_wgrad in lcao_mfma.hip,
+// pair-table gradient: lcao_pair_table_grad below).
 //
 // Notation as in lcaonet_amd/model/lcaonet.py (p-space edges, species-pair table Tf, Gram form of the three-body
 // normalisation).  g_X denotes dE/dX.  Dense layers are differentiated with lcao_dense on transposed weights; the

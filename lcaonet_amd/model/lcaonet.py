@@ -343,9 +343,8 @@ class LCAOOut(nn.Module):
             x = x.contiguous()
             force_st = run_mlp(self.out_lin_force, torch.cat([x[idx_s], x[idx_t]], dim=-1)) * edge_vec_st
             return prop, scatter(force_st, idx_s, dim=0, dim_size=x.size(0))
-        raise NotImplementedError(
-            "regress_forces with direct_forces=False needs -dE/dpos through the HIP kernels; their backward "
-            "pass is not built yet (SURVEY.md §8f-3)")
+        # F = -dE/dpos needs the whole model, not this head: LCAONet.forward routes it to model/forces.py
+        raise NotImplementedError("LCAOOut alone cannot produce autograd forces; call LCAONet.forward")
 
 
 class LCAONet(BaseMPNN):
@@ -437,7 +436,7 @@ class LCAONet(BaseMPNN):
         from .. import shard
 
         if self.regress_forces and not self.direct_forces:
-            raise NotImplementedError("autograd forces: backward kernels not built yet (SURVEY.md §8f-3)")
+            raise NotImplementedError("forward_sharded: autograd forces need a reverse halo exchange, which is not built")
         if self.training:
             raise NotImplementedError("forward_sharded: eval mode only (BatchNorm batch statistics would need a collective)")
         exchange_fn = exchange_fn or (lambda x_own: shard.exchange_ghosts(plan, x_own, group))
