@@ -192,6 +192,13 @@ int lcao_pair_contract(const float* Tf, const float* rb, const int32_t* order, c
                        const int32_t* src_p, const int32_t* dst_p, const float* gate, int64_t n_edges, int n_orb, int V,
                        int n_l, int zdim, float* Ag, float* B, float* gram, void* stream);
 
+/* lcao_pair_contract walking the edges in the order visit[0..n_edges) (a permutation of p-space, e.g. edges sorted by
+ * species pair so that neighbouring waves share table blocks in L1).  Same inputs, same outputs at the same rows. */
+int lcao_pair_contract_visit(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                             const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
+                             const int32_t* visit, int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* Ag,
+                             float* B, float* gram, void* stream);
+
 /* lcaonet.py:192-204 + basis_weight (:209) in ONE kernel (no valence):
  *   bw[p,:] = normalize( (1 + tbw[p,:] W3^T) * B[p,:] ) Wb^T          W3, Wb (V, V) */
 int lcao_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges, int V,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "lcao_coeff_mlp_contract_bf16x3": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, c_size_t, P],
     "lcao_triplet_gemm": [P, P, P, P, P, P, L, L, I, I, P, P],
     "lcao_pair_contract": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],
+    "lcao_pair_contract_visit": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],
     "lcao_edge_lcao_weight": [P, P, P, P, L, I, P, P],
     "lcao_edge_node_message": [P, P, P, P, P, P, P, L, I, P, P],
     "lcao_edge_lcao_weight_saving": [P, P, P, P, L, I, P, P, P],

@@ -604,15 +604,19 @@ __global__ __launch_bounds__(256) void k_pair_contract(const float* __restrict__
                                                        const int32_t* __restrict__ dst_p,
                                                        const float* __restrict__ gate, int64_t E, int D, int zdim,
                                                        float* __restrict__ Ag, float* __restrict__ B,
-                                                       float* __restrict__ gram) {
+                                                       float* __restrict__ gram,
+                                                       const int32_t* __restrict__ visit /* or null */) {
   constexpr int NC = (V + 63) / 64;  // float4 chunks per lane
   const int sub = threadIdx.x & 15, rowi = (threadIdx.x & 63) >> 4;
   int64_t p0 = ((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) * 4;   // wave-uniform: 4 edges per wave
   const int64_t stride = (((int64_t)gridDim.x * blockDim.x) >> 6) * 4;
   for (; p0 < E; p0 += stride) {   // whole waves stay converged for the DPP reductions; rows past E are masked
-    const int64_t p = p0 + rowi;
-    const bool valid = p < E;
-    const int64_t pc = valid ? p : E - 1;
+    const int64_t pi = p0 + rowi;
+    const bool valid = pi < E;
+    // visit: the order in which edges are WALKED (e.g. sorted by species pair, so that the four edges of a wave and the
+    // waves of a workgroup read the same 4 KB table block from L1 instead of L2); every read and write stays indexed by p
+    const int64_t p = visit ? (int64_t)visit[valid ? pi : E - 1] : pi;
+    const int64_t pc = valid ? p : (visit ? p : E - 1);
     const int64_t e = order ? order[pc] : pc;
     const int s = src_p[pc];
     const int64_t pair = z[s] * zdim + z[dst_p[pc]];
@@ -672,10 +676,11 @@ __global__ __launch_bounds__(256) void k_pair_contract(const float* __restrict__
           f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int l = 0; l < NL; ++l) {
-            *(f32x4*)(Ag + (p * NL + l) * V + 64 * c + 4 * sub) = a[l][c] * gg;
+            // streaming stores: 2.4 GB per launch that nothing re-reads before it has left every cache
+            __builtin_nontemporal_store(a[l][c] * gg, (f32x4*)(Ag + (p * NL + l) * V + 64 * c + 4 * sub));
             bsum += a[l][c];
           }
-          *(f32x4*)(B + p * V + 64 * c + 4 * sub) = bsum;
+          __builtin_nontemporal_store(bsum, (f32x4*)(B + p * V + 64 * c + 4 * sub));
         }
       }
     }
@@ -745,10 +750,32 @@ __global__ void k_pair_contract_any(const float* __restrict__ Tf, const float* _
   }
 }
 
+static int launch_pair_contract(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                                const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
+                                int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* Ag, float* B, float* gram,
+                                const int32_t* visit, void* stream);
+
 extern "C" int lcao_pair_contract(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
                                   const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
                                   int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* Ag, float* B, float* gram,
                                   void* stream) {
+  return launch_pair_contract(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_edges, n_orb, V, n_l, zdim, Ag, B, gram,
+                              nullptr, stream);
+}
+
+extern "C" int lcao_pair_contract_visit(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                                        const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
+                                        const int32_t* visit, int64_t n_edges, int n_orb, int V, int n_l, int zdim,
+                                        float* Ag, float* B, float* gram, void* stream) {
+  if (V != 128 && V != 64 && V != 32) return LCAO_ERR_UNSUPPORTED;   // the any-V kernel walks edges in p order
+  return launch_pair_contract(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_edges, n_orb, V, n_l, zdim, Ag, B, gram,
+                              visit, stream);
+}
+
+static int launch_pair_contract(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d,
+                                const int64_t* z, const int32_t* src_p, const int32_t* dst_p, const float* gate,
+                                int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* Ag, float* B, float* gram,
+                                const int32_t* visit, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   if (n_orb <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
@@ -759,7 +786,7 @@ extern "C" int lcao_pair_contract(const float* Tf, const float* rb, const int32_
 #define PC_CASE(V_, NL_)                                                                                          \
   if (V == V_ && n_l == NL_) {                                                                                    \
     hipLaunchKernelGGL((k_pair_contract<V_, NL_>), grid, block, 0, st, Tf, rb, order, l_of_d, z, src_p, dst_p, gate, \
-                       n_edges, n_orb, zdim, Ag, B, gram);                                                        \
+                       n_edges, n_orb, zdim, Ag, B, gram, visit);                                                 \
     return lcao_launch_status();                                                                                  \
   }
 #define PC_V(V_) PC_CASE(V_, 1) PC_CASE(V_, 2) PC_CASE(V_, 3) PC_CASE(V_, 4)

@@ -157,7 +157,8 @@ class LCAOStackFn(torch.autograd.Function):
             Ps = ops.dense(xs, Wn1[:, :V].contiguous(), bn1)
             Pt = ops.dense(xs, Wn1[:, V:].contiguous())
             Tf = Tfs[i].detach().contiguous()
-            pc = lambda T: ops.pair_contract(T, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, gate, geom.n_l, geom.zd)
+            pc = lambda T: ops.pair_contract(T, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, gate, geom.n_l, geom.zd,
+                                             visit=geom.perm_pair)   # edges walked pair by pair: table blocks stay in L1
             valence = Tf.shape[-1] == 2 * V     # add_valence: [plain half | masked valence half] (lcaonet.py:174-183)
             Bv = None
             if valence:

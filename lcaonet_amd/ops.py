@@ -263,8 +263,9 @@ def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence,
     return (Ag if gated else A), gram, B, Bv
 
 
-def pair_contract(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_l, zdim):
-    """Tf ((zdim*zdim), D, V) pair table -> (Ag, gram, B) like coeff_mlp_contract(gate=...)."""
+def pair_contract(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_l, zdim, visit=None):
+    """Tf ((zdim*zdim), D, V) pair table -> (Ag, gram, B) like coeff_mlp_contract(gate=...).
+    visit: optional int32 permutation of p-space giving the order in which edges are walked (sorted by species pair)."""
     Tf, rb, gate = _f32(Tf, "Tf"), _f32(rb, "rb"), _f32(gate, "gate")
     z = _i64(z)
     E, D = rb.shape
@@ -273,6 +274,10 @@ def pair_contract(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_l, zdim):
     Ag = torch.empty(E, n_l, V, device=dev, dtype=torch.float32)
     B = torch.empty(E, V, device=dev, dtype=torch.float32)
     gram = torch.empty(E, 10, device=dev, dtype=torch.float32)
+    if visit is not None and V in FUSED_WIDTHS:
+        _call("lcao_pair_contract_visit", _p(Tf), _p(rb), _p(order), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate),
+              _p(visit), E, D, V, n_l, zdim, _p(Ag), _p(B), _p(gram), _stream())
+        return Ag, gram, B
     _call("lcao_pair_contract", _p(Tf), _p(rb), _p(order), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate), E, D, V,
           n_l, zdim, _p(Ag), _p(B), _p(gram), _stream())
     return Ag, gram, B
