@@ -100,6 +100,10 @@ int lcao_dense(const float* X, int64_t ldx, const float* W, const float* bias, c
  * (b nullable => plain segment sum).  Call sites lcaonet.py:189,208-213,293,307.  Deterministic (no atomics). */
 int lcao_segment_sum(const float* a, const float* b, const int32_t* ptr, int64_t n_seg, int width, float* out,
                      void* stream);
+/* out[s,:] = sum_{r in [ptr[s], ptr[s+1])} a[idx[r],:] — the same sum over a LIST of rows (e.g. the in-edges of a node,
+ * idx = in_pos), i.e. lcao_permute_rows + lcao_segment_sum in one pass. */
+int lcao_segment_sum_gather(const float* a, const int32_t* idx, const int32_t* ptr, int64_t n_seg, int width, float* out,
+                            void* stream);
 
 /* rows gather: out[i,:] = table[idx[i],:]  (x[idx_s], embedding lookups) */
 int lcao_gather_rows(const float* table, const int64_t* idx, int64_t n, int width, float* out, void* stream);

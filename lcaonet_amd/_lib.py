@@ -28,6 +28,7 @@ SIGNATURES = {
     "lcao_nl_search": [P, P, P, P, P, P, L, F, I, P, P, P, P, P, P, P],
     "lcao_dense": [P, L, P, P, P, L, P, L, L, I, I, I, P],
     "lcao_segment_sum": [P, P, P, L, I, P, P],
+    "lcao_segment_sum_gather": [P, P, P, L, I, P, P],
     "lcao_gather_rows": [P, P, L, I, P, P],
     "lcao_permute_rows": [P, P, L, I, P, P],
     "lcao_coeff_contract": [P, P, P, P, P, L, L, L, L, I, I, I, I, P, P, P, P],

@@ -209,15 +209,94 @@ __global__ void k_segment_sum(const float* __restrict__ a, const float* __restri
   }
 }
 
-extern "C" int lcao_segment_sum(const float* a, const float* b, const int32_t* ptr, int64_t n_seg, int width,
-                                float* out, void* stream) {
+// 16-byte form for widths 4*WL, WL in {8, 16, 32, 64} lanes per row: 64/WL rows per load instruction, two running sums
+// per lane, then a fixed shuffle tree over the row groups (deterministic; the association differs from the row-by-row
+// kernel above, not from run to run).  idx (optional): row r of the segment list is a[idx[r]] — a gather fused into the sum.
+template <int WL>
+__global__ void k_segment_sum_v4(const float* __restrict__ a, const float* __restrict__ b,
+                                 const int32_t* __restrict__ idx, const int32_t* __restrict__ ptr, int64_t n_seg,
+                                 float* __restrict__ out) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int RP = 64 / WL, width = 4 * WL;
+  const int lane = threadIdx.x & 63, g = lane / WL, cl = lane % WL;
+  int64_t seg = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; seg < n_seg; seg += nwave) {
+    const int r0 = ptr[seg], r1 = ptr[seg + 1];
+    f4 s0 = f4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int r = r0 + g;
+    for (; r + RP < r1; r += 2 * RP) {
+      const int64_t ra = idx ? idx[r] : r, rb_ = idx ? idx[r + RP] : r + RP;
+      f4 va = *(const f4*)(a + ra * width + 4 * cl), vb = *(const f4*)(a + rb_ * width + 4 * cl);
+      if (b) { va *= *(const f4*)(b + ra * width + 4 * cl); vb *= *(const f4*)(b + rb_ * width + 4 * cl); }
+      s0 += va;
+      s1 += vb;
+    }
+    if (r < r1) {
+      const int64_t ra = idx ? idx[r] : r;
+      f4 va = *(const f4*)(a + ra * width + 4 * cl);
+      if (b) va *= *(const f4*)(b + ra * width + 4 * cl);
+      s0 += va;
+    }
+    s0 += s1;
+#pragma unroll
+    for (int off = 32; off >= WL; off >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s0[k] += __shfl_xor(s0[k], off);
+    }
+    if (g == 0) *(f4*)(out + seg * width + 4 * cl) = s0;
+  }
+}
+
+__global__ void k_segment_sum_idx(const float* __restrict__ a, const int32_t* __restrict__ idx,
+                                  const int32_t* __restrict__ ptr, int64_t n_seg, int width, float* __restrict__ out) {
+  int lane = threadIdx.x & 63;
+  int64_t seg = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (; seg < n_seg; seg += nwave) {
+    int r0 = ptr[seg], r1 = ptr[seg + 1];
+    for (int c = lane; c < width; c += 64) {
+      float acc = 0.0f;
+      for (int r = r0; r < r1; ++r) acc += a[(int64_t)idx[r] * width + c];
+      out[seg * width + c] = acc;
+    }
+  }
+}
+
+static int launch_segment_sum(const float* a, const float* b, const int32_t* idx, const int32_t* ptr, int64_t n_seg,
+                              int width, float* out, void* stream) {
   LCAO_CHECK_SIZE(n_seg);
   if (width <= 0) return LCAO_ERR_INVALID;
   if (n_seg == 0) return LCAO_OK;
   LCAO_CHECK_PTR(a); LCAO_CHECK_PTR(ptr); LCAO_CHECK_PTR(out);
-  hipLaunchKernelGGL(k_segment_sum, dim3(lcao_blocks(n_seg, 4, 16384)), dim3(256), 0, (hipStream_t)stream, a, b,
-                     ptr, n_seg, width, out);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n_seg, 4, 16384)), block(256);
+  const bool al = (((uintptr_t)a | (uintptr_t)out | (uintptr_t)(b ? b : a)) % 16) == 0;
+#define SS_CASE(WL_)                                                                                        \
+  if (al && width == 4 * WL_) {                                                                             \
+    hipLaunchKernelGGL(k_segment_sum_v4<WL_>, grid, block, 0, st, a, b, idx, ptr, n_seg, out);              \
+    return lcao_launch_status();                                                                            \
+  }
+  SS_CASE(8) SS_CASE(16) SS_CASE(32) SS_CASE(64)
+#undef SS_CASE
+  if (idx) {
+    if (b) return LCAO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_segment_sum_idx, grid, block, 0, st, a, idx, ptr, n_seg, width, out);
+  } else {
+    hipLaunchKernelGGL(k_segment_sum, grid, block, 0, st, a, b, ptr, n_seg, width, out);
+  }
   return lcao_launch_status();
+}
+
+extern "C" int lcao_segment_sum(const float* a, const float* b, const int32_t* ptr, int64_t n_seg, int width,
+                                float* out, void* stream) {
+  return launch_segment_sum(a, b, nullptr, ptr, n_seg, width, out, stream);
+}
+
+extern "C" int lcao_segment_sum_gather(const float* a, const int32_t* idx, const int32_t* ptr, int64_t n_seg, int width,
+                                       float* out, void* stream) {
+  if (n_seg > 0) LCAO_CHECK_PTR(idx);
+  return launch_segment_sum(a, nullptr, idx, ptr, n_seg, width, out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

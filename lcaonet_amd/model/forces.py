@@ -29,7 +29,7 @@ def _t(w: Tensor) -> Tensor:
 
 def _in_sum(rows: Tensor, ctx, n_nodes: int) -> Tensor:
     """sum of per-edge rows over the IN-edges of every node (deterministic: in_pos order)."""
-    return ops.segment_sum(ops.gather_rows(rows, ctx.in_pos), ctx.in_ptr[: n_nodes + 1])
+    return ops.segment_sum_gather(rows, ctx.in_pos, ctx.in_ptr[: n_nodes + 1])
 
 
 @torch.no_grad()

@@ -228,7 +228,7 @@ class LCAOStackFn(torch.autograd.Function):
             gp[i * 9 + 7] = g_pre2.sum(0)
             del h1, g_pre2
             g_Ps = ops.segment_sum(g_pre1, ctx.out_ptr)
-            g_Pt = ops.segment_sum(ops.gather_rows(g_pre1, ctx.in_pos), ctx.in_ptr)
+            g_Pt = ops.segment_sum_gather(g_pre1, ctx.in_pos, ctx.in_ptr)
             lw = ops.edge_combine(sv["ft"], sv["B"], sv["Bv"])
             gp[i * 9 + 3] = _mm_t(g_bw, lw)
             del lw
@@ -272,7 +272,7 @@ class LCAOStackFn(torch.autograd.Function):
             gp[i * 9 + 0] = _mm_t(g_nw, sv["x"])
             gp[i * 9 + 1] = g_nw.sum(0)
             g_x = ops.dense(g_nw, Wnw.t().contiguous(), None, ops.ACT_NONE, g_x)
-        g_x_tab = ops.segment_sum(ops.gather_rows(g_x, geom.order_z.to(torch.int32)), geom.ptr_z)
+        g_x_tab = ops.segment_sum_gather(g_x, geom.order_z.to(torch.int32), geom.ptr_z)
         return (None, None, g_x_tab.reshape(fctx.x_tab_shape), *g_Tf, *g_params)
 
 

@@ -186,6 +186,18 @@ def segment_sum(a: Tensor, ptr: Tensor, b: Tensor | None = None) -> Tensor:
     return out
 
 
+def segment_sum_gather(a: Tensor, idx: Tensor, ptr: Tensor) -> Tensor:
+    """out[s] = sum of a[idx[r]] over r in [ptr[s], ptr[s+1]) — gather_rows + segment_sum in one pass."""
+    a, idx, ptr = _f32(a, "a"), _i32(idx, "idx"), _i32(ptr, "ptr")
+    n_seg = ptr.numel() - 1
+    width = a.shape[1] if a.dim() > 1 else 1
+    if a.shape[0] == 0 or idx.numel() == 0:
+        return torch.zeros((n_seg, width), device=a.device, dtype=torch.float32)
+    out = torch.empty((n_seg, width), device=a.device, dtype=torch.float32)
+    _call("lcao_segment_sum_gather", _p(a), _p(idx), _p(ptr), n_seg, width, _p(out), _stream())
+    return out
+
+
 def gather_rows(table: Tensor, idx: Tensor) -> Tensor:
     table = _f32(table, "table")
     width = int(table[0].numel()) if table.shape[0] > 0 else int(torch.tensor(table.shape[1:]).prod())
