@@ -626,6 +626,96 @@ def test_parameter_gradients_vs_oracle_autograd(dev, width, training, valence):
         assert int(m.emb_layer.coeff_embed.bn.num_batches_tracked) == 1
 
 
+def _reference_model_grid():
+    """The constructor combinations the reference's own model test walks through (tests/model/test_lcaonet.py:70-131),
+    regenerated from its structure: a boolean block, cutoff networks, widths, n_per_orb, max_orb, radial bases,
+    mean / atomref post-processing, and both force modes."""
+    base = dict(emb_size=16, emb_size_coeff=16, emb_size_conv=10, out_size=1, n_per_orb=1, cutoff=6.0,
+                cutoff_net="envelope", max_orb=None, elec_to_node=True, add_valence=False, extend_orb=False,
+                is_extensive=True, rbf_type="hydrogen", mean=None, atomref=False, regress_forces=False, direct_forces=True)
+    grid = []
+    for e2n in (True, False):
+        for val in (False, True):
+            for ext in (False, True):
+                for extensive in (True, False):
+                    grid.append(dict(base, elec_to_node=e2n, add_valence=val, extend_orb=ext, is_extensive=extensive))
+    for net in ("polynomial", "cosine", "envelope"):
+        grid.append(dict(base, cutoff_net=net))
+        grid.append(dict(base, cutoff_net=net, cutoff=2.0, add_valence=True, extend_orb=True))
+    dims = dict(emb_size=10, emb_size_coeff=32, emb_size_conv=16, out_size=2)
+    grid += [dict(base, emb_size=32), dict(base, emb_size_coeff=32), dict(base, emb_size=10, emb_size_conv=32),
+             dict(base, **dims), dict(base, **dims, add_valence=True, extend_orb=True)]
+    grid += [dict(base, n_per_orb=2), dict(base, n_per_orb=2, add_valence=True, extend_orb=True),
+             dict(base, **dims, n_per_orb=2)]
+    grid += [dict(base, n_per_orb=2, max_orb=mo) for mo in ("4p", "3s", "1s")]
+    grid += [dict(base, n_per_orb=2, max_orb="4p", add_valence=True, extend_orb=True), dict(base, **dims, max_orb="3s")]
+    bes = dict(base, cutoff=2.0, rbf_type="sphericalbessel")
+    grid += [bes, dict(bes, max_orb="4p"), dict(bes, n_per_orb=2), dict(bes, n_per_orb=2, add_valence=True, extend_orb=True),
+             dict(bes, n_per_orb=2, max_orb="4p", add_valence=True, extend_orb=True)]
+    for mean, aref in ((True, False), (False, True), (True, True)):
+        for extensive in (True, False):
+            grid.append(dict(base, cutoff=2.0, mean=mean or None, atomref=aref, is_extensive=extensive))
+    grid += [dict(base, regress_forces=True, direct_forces=True), dict(base, regress_forces=True, direct_forces=False)]
+    return grid
+
+
+@pytest.mark.parametrize("idx", range(len(_reference_model_grid())))
+def test_reference_constructor_grid(dev, idx):
+    """Every constructor combination of the reference's model test on its 3-atom / 8-edge fixture graph: output
+    shapes, parity with the oracle on the same weights (the reference checks TorchScript self-consistency there), and
+    its trainability criterion (Adam, MSE to ones, min loss < 2).  Training on AUTOGRAD forces needs a double backward,
+    which is not built: that single combination must refuse loudly."""
+    from lcaonet_amd.data.synthetic import reference_fixture_graph
+    from lcaonet_amd.model import LCAONet
+    kw = dict(_reference_model_grid()[idx])
+    g_cpu = reference_fixture_graph()
+    max_z = int(g_cpu["z"].max())
+    out_size = kw["out_size"]
+    mean = torch.tensor([1.0] * out_size) if kw.pop("mean") else None
+    aref = torch.ones(max_z + 1, out_size) if kw.pop("atomref") else None
+    kw.update(n_interaction=2, max_z=max_z, activation="SiLU", weight_init="glorotorthogonal")
+    torch.manual_seed(1000 + idx)
+    m = LCAONet(mean=mean, atomref=aref, **kw).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    if mean is not None:
+        sd["pp_layer.mean"] = mean
+    if aref is not None:
+        sd["pp_layer.atomref"] = aref
+    okw = {k: v for k, v in kw.items() if k not in ("activation", "weight_init")}
+    forces = kw["regress_forces"]
+    want = O.forward(sd, _ocfg(okw), g_cpu.to_dict(), dtype=torch.float64 if forces and not kw["direct_forces"] else torch.float32)
+    m = m.to(dev)
+    g = g_cpu.to(dev)
+    got = m(g)
+    n_atoms = g_cpu["pos"].shape[0]
+    if forces:
+        assert len(got) == 2 and got[0].shape == (1, out_size) and got[1].shape == (n_atoms, 3)
+        assert relerr(got[0], want[0].detach()) <= TOL and relerr(got[1], want[1].detach()) <= 5 * TOL
+    else:
+        assert got.shape == (1, out_size)
+        assert relerr(got, want) <= TOL
+    # trainability (reference :216-243), 25 Adam steps instead of 100
+    m.train()
+    if forces and not kw["direct_forces"]:
+        with pytest.raises(NotImplementedError):
+            m(g)
+        return
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    best = float("inf")
+    for _ in range(25):
+        opt.zero_grad()
+        out = m(g)
+        if forces:
+            loss = 0.001 * torch.nn.functional.mse_loss(out[0], torch.ones(1, out_size, device=dev)) + \
+                0.999 * torch.nn.functional.mse_loss(out[1], torch.ones(n_atoms, 3, device=dev))
+        else:
+            loss = torch.nn.functional.mse_loss(out, torch.ones(1, out_size, device=dev))
+        loss.backward()
+        opt.step()
+        best = min(best, float(torch.nan_to_num(loss.detach())))
+    assert best < 2
+
+
 def test_segment_sum_kernels(dev):
     """lcao_segment_sum (+ optional row-wise multiplier) and lcao_segment_sum_gather against index_add in fp64: the 16-byte
     kernels (widths 32 / 64 / 128 / 256), the scalar kernels (3, 20, 1024), empty and very long segments; bitwise
