@@ -133,8 +133,8 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     return g_x
 
 
-def _check_supported(model):
-    if model.training:
+def _check_supported(model, have_tables: bool = False):
+    if model.training and not have_tables:
         raise NotImplementedError("autograd forces: eval mode only (BatchNorm batch statistics are not differentiated)")
     acts = [model.int_layers[0].f_coeffs[1], model.int_layers[0].f_node[1], model.out_layer.out_lin[1]]
     if not all(type(a) is nn.SiLU for a in acts):
@@ -144,13 +144,15 @@ def _check_supported(model):
 
 
 @torch.no_grad()
-def forward_with_autograd_forces(model, graph):
+def forward_with_autograd_forces(model, graph, tables=None):
     """Returns (out (B, out_size), force) with force = -d(sum_b out[b, i])/dpos: (N, 3) for out_size == 1,
-    (N, out_size, 3) otherwise — the shapes of lcaonet.py:310-317."""
+    (N, out_size, 3) otherwise — the shapes of lcaonet.py:310-317.
+    tables = (x_tab (max_z+1, H), cst_pair, zdim): embedding tables supplied by the caller (model/train.py: train-mode
+    BatchNorm batch statistics) instead of the eval-mode ones."""
     from .lcaonet import EdgeContext
     from .base import BaseMPNN
 
-    _check_supported(model)
+    _check_supported(model, tables is not None)
     batch_idx = graph.get(GraphKeys.Batch_idx)
     z, pos = graph[GraphKeys.Z], graph[GraphKeys.Pos]
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
@@ -161,7 +163,10 @@ def forward_with_autograd_forces(model, graph):
     dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
     uvec_p = ctx.uvec_p(uvec)
     rb = model.rbf(dist)
-    x, cst_pair, zdim = model.emb_layer.forward_pair_table(z)
+    if tables is None:
+        x, cst_pair, zdim = model.emb_layer.forward_pair_table(z)
+    else:
+        x, cst_pair, zdim = ops.gather_rows(tables[0], z), tables[1], tables[2]
     l_of_d, n_l = model.shbf.l_of_d, model.n_l
 
     mask_pair = model.pair_valence_mask(zdim) if model.add_valence else None
