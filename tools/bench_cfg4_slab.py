@@ -1,0 +1,52 @@
+"""BASELINE config 4 at FULL scale, one rank's share measured on one GPU: build the 126^3 = 2 000 376-atom periodic crystal
+(cutoff 6.0, <= 32 nearest neighbours) on the device, partition it into 8 slabs (shard.make_plans) and time rank r's
+forward_sharded — its owned slab plus the replicated halo edges — with the boundary exchange replaced by a local stand-in
+(no other ranks exist here; the exchange itself is one all-gather of the printed size per interaction).
+usage: python tools/bench_cfg4_slab.py [rank] [steps]"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import WORKLOADS, build_model
+from lcaonet_amd import shard
+from lcaonet_amd.data.synthetic import jittered_cubic_crystal
+
+rank = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+t0 = time.perf_counter()
+g = jittered_cubic_crystal(126, cutoff_graph=5.94, max_neighbors=32, device=dev)
+torch.cuda.synchronize()
+N, E = g["z"].numel(), g["edge_index"].shape[1]
+print(f"crystal: N={N} E={E} ({E / N:.1f} neighbours) built on the GPU in {time.perf_counter() - t0:.2f} s", flush=True)
+t0 = time.perf_counter()
+plans = shard.make_plans(g, 8)
+torch.cuda.synchronize()
+print(f"8 slab plans in {time.perf_counter() - t0:.2f} s: " + ", ".join(
+    f"r{p.rank}: own {p.n_own} ghost {p.n_ghost} e_own {p.e_own} e_local {p.graph['edge_index'].shape[1]}" for p in plans[:2]) + " ...",
+    flush=True)
+plan = plans[rank]
+del plans, g
+torch.cuda.empty_cache()
+model = build_model(WORKLOADS["cfg4-1of8"][1], 1234, dev)
+H = model.emb_size
+ghost_rows = torch.randn(plan.n_ghost, H, device=dev)
+calls = [0]
+def fake_exchange(x_own):      # what exchange_ghosts returns: the (n_ghost, H) rows of this rank's ghosts
+    calls[0] += 1
+    return ghost_rows
+with torch.no_grad():
+    for _ in range(2):
+        out = model.forward_sharded(plan, exchange_fn=fake_exchange, reduce_fn=lambda part: part)
+    torch.cuda.synchronize()
+    calls[0] = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model.forward_sharded(plan, exchange_fn=fake_exchange, reduce_fn=lambda part: part)
+    torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / steps * 1e3
+e_loc = plan.graph["edge_index"].shape[1]
+print(f"rank {rank}: {ms:.1f} ms per forward for e_own={plan.e_own} owned edges (+{e_loc - plan.e_own} replicated halo edges, "
+      f"{100.0 * (e_loc - plan.e_own) / plan.e_own:.1f} %) = {plan.e_own / ms * 1e3 / 1e6:.1f} M owned edges/s per GPU")
+print(f"exchange per interaction: all-gather of {plan.max_send} boundary rows x {H} fp32 = {plan.max_send * H * 4 / 1e6:.1f} MB per rank "
+      f"({calls[0] // steps} exchanges per forward); peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+print(f"whole crystal on 8 such ranks (projection, not measured): {E / ms * 1e3 / 1e6:.0f} M edges/s")
