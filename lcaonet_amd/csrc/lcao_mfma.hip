@@ -24,6 +24,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 //   LCAO_ABL & 1: activations replaced by identity     & 2: coefficient rows loaded once per tile, not per orbital
 //   LCAO_ABL & 4: weight fragments read once per feature-tile pair instead of once per k chunk (1/KT of the LDS reads)
 //   LCAO_ABL & 8: WITHOUT the s_setprio(1) around each layer's MFMA stream     & 16: static s_setprio(1) for waves 4-7
+//   LCAO_ABL & 128 / & 256 / & 512 (k_triplet_bwd_mfma): GEMM 1 cut to one k chunk / no scalar chain / GEMM 2 cut to one tile
 //   LCAO_ABL & 32 / & 64 (k_triplet_gemm, tools/k3_ablate.py): no Y_l / norm arithmetic / one MFMA per in-edge step
 #ifndef LCAO_ABL
 #define LCAO_ABL 0
@@ -1302,6 +1303,16 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
         f32x4v gw[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) gw[l] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#if LCAO_ABL & 128
+        {  // diagnostic: one k chunk instead of KT
+          const f32x4v xa = *(const f32x4v*)(gta);
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            const f32x4v xb = *(const f32x4v*)(agq + l * V);
+            gw[l] = MFMA16(xa[0], xb[0], gw[l]);
+          }
+        }
+#else
 #pragma unroll
         for (int a = 0; a < KT; ++a) {
           const f32x4v xa = *(const f32x4v*)(gta + 16 * a);
@@ -1312,6 +1323,7 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
             for (int b = 0; b < 4; ++b) gw[l] = MFMA16(xa[b], xb[b], gw[l]);
           }
         }
+#endif
         // ---- scalar chain for this lane's 4 pairs (p = it + 4*quarter + r, q)
         float w[NL][4];
         float gpx[4], gpy[4], gpz[4];
@@ -1321,6 +1333,14 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
           const int p = p0 + min(pi, m_out - 1);
           const bool ok = qv && pi < m_out && p != q;
           const float px = uvec_p[3 * (int64_t)p], py = uvec_p[3 * (int64_t)p + 1], pz = uvec_p[3 * (int64_t)p + 2];
+#if LCAO_ABL & 256
+          {  // diagnostic: no per-pair scalar chain
+#pragma unroll
+            for (int l = 0; l < NL; ++l) w[l][r] = ok ? gw[l][r] * G[0] : 0.f;
+            gpx[r] = gpy[r] = gpz[r] = px * qx;
+            continue;
+          }
+#endif
           const float c = px * qx + py * qy + pz * qz;
           float y[4], dy[4], GY[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1364,17 +1384,40 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
             o[0] += sx; o[1] += sy; o[2] += sz;
           }
         }
-        // ---- GEMM 2: gA[l][t] (channel 16t + 4*quarter + r', in-edge n) += sum_p g_tbw[p][channel] w[l][p, q_n]
-        //      k-step r: quarter `quarter` contributes p = it + 4*quarter + r (B operand = w[l][r])
+        // ---- GEMM 2: gA[l][t] (channel row, in-edge n) += sum_p g_tbw[p][channel] w[l][p, q_n]
+        //      k-step r: quarter `quarter` contributes p = it + 4*quarter + r (B operand = w[l][r]).
+        //      V >= 64: the A operand is read as float4 (channels 64h + 4n .. +3); its four floats feed the four channel
+        //      tiles 4h + j, so tile 4h + j holds channels 64h + 4i + j in its rows i (a permuted tiling that the store
+        //      below undoes) — 2 x 16-B loads per k-step instead of 8 x 4-B.
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pr = p0 + min(it + 4 * quarter + r, m_out - 1);
-          const float* gtr = g_tbw + (int64_t)pr * V + n;
+          if constexpr (V >= 64) {
+            const float* gtr = g_tbw + (int64_t)pr * V + 4 * n;
+#if LCAO_ABL & 512
+            {
+              const f32x4v av = *(const f32x4v*)(gtr);
 #pragma unroll
-          for (int t = 0; t < KT; ++t) {
-            const float av = gtr[16 * t];
+              for (int l = 0; l < NL; ++l) gA[l][0] = MFMA16(av[0], w[l][r], gA[l][0]);
+            }
+#else
 #pragma unroll
-            for (int l = 0; l < NL; ++l) gA[l][t] = MFMA16(av, w[l][r], gA[l][t]);
+            for (int h = 0; h < V / 64; ++h) {
+              const f32x4v av = *(const f32x4v*)(gtr + 64 * h);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) gA[l][4 * h + j] = MFMA16(av[j], w[l][r], gA[l][4 * h + j]);
+            }
+#endif
+          } else {
+            const float* gtr = g_tbw + (int64_t)pr * V + n;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              const float av = gtr[16 * t];
+#pragma unroll
+              for (int l = 0; l < NL; ++l) gA[l][t] = MFMA16(av, w[l][r], gA[l][t]);
+            }
           }
         }
       }
@@ -1390,11 +1433,25 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
           for (int i = 0; i < 10; ++i) g_gram[(int64_t)q * 10 + i] = gG[i];
           g_uq[3 * (int64_t)q] = gqx; g_uq[3 * (int64_t)q + 1] = gqy; g_uq[3 * (int64_t)q + 2] = gqz;
         }
-        float* go = g_Ag + (int64_t)q * NL * V + 4 * quarter;
+        if constexpr (V >= 64) {
+          // tile 4h + j, accumulator register rr of lane (q, quarter): channel 64h + 4 (4 quarter + rr) + j
+          float* go = g_Ag + (int64_t)q * NL * V + 16 * quarter;
 #pragma unroll
-        for (int l = 0; l < NL; ++l)
+          for (int l = 0; l < NL; ++l)
 #pragma unroll
-          for (int t = 0; t < KT; ++t) *(f32x4v*)(go + l * V + 16 * t) = gA[l][t];
+            for (int h = 0; h < V / 64; ++h)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) {
+                const f32x4v v = f32x4v{gA[l][4 * h][rr], gA[l][4 * h + 1][rr], gA[l][4 * h + 2][rr], gA[l][4 * h + 3][rr]};
+                *(f32x4v*)(go + l * V + 64 * h + 4 * rr) = v;
+              }
+        } else {
+          float* go = g_Ag + (int64_t)q * NL * V + 4 * quarter;
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) *(f32x4v*)(go + l * V + 16 * t) = gA[l][t];
+        }
       }
     }
   }

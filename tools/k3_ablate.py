@@ -1,4 +1,5 @@
-"""Time lcao_triplet_gemm (cfg2 graph) for diagnostic builds in tools/abl/ (LCAO_ABL & 32: no weight arithmetic, & 64: one MFMA per step)."""
+"""Time lcao_triplet_gemm and lcao_triplet_bwd_mfma (cfg2 graph) for diagnostic builds in tools/abl/
+(LCAO_ABL & 32: no weight arithmetic, & 64: one MFMA per step; & 128 / 256 / 512: backward GEMM 1 / scalar chain / GEMM 2 cut)."""
 import ctypes, glob, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,4 +33,15 @@ for path in sorted(glob.glob(sys.argv[1] + "/lib*.so")):
     for _ in range(20): run()
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
-    print(f"{os.path.basename(path):12s} {ms:7.3f} ms  {(4*NL*V+52+4*V)*E/ms/1e6:7.1f} GB/s")
+    print(f"{os.path.basename(path):12s} triplet_gemm {ms:7.3f} ms  {(4*NL*V+52+4*V)*E/ms/1e6:7.1f} GB/s", end="   ")
+    fb = lib.lcao_triplet_bwd_mfma
+    fb.argtypes = _lib.SIGNATURES["lcao_triplet_bwd_mfma"]
+    g_tbw = torch.randn(E, V, device=dev, generator=gen)
+    g_Ag = torch.empty_like(Ag); g_gram = torch.empty(E, 10, device=dev); g_uq = torch.empty(E, 3, device=dev); g_up = torch.empty(E, 3, device=dev)
+    runb = lambda: fb(p(g_tbw), p(Ag), p(gram10), p(u), p(ctx.in_ptr), p(ctx.in_pos), p(ctx.out_ptr), N, E, V, NL, p(g_Ag), p(g_gram), p(g_uq), p(g_up), None)
+    for _ in range(2): assert runb() == 0
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(10): runb()
+    b.record(); torch.cuda.synchronize()
+    print(f"triplet_bwd_mfma {a.elapsed_time(b) / 10:7.3f} ms")

@@ -7,6 +7,8 @@ from lcaonet_amd.data.synthetic import jittered_cubic_cells
 
 dev = torch.device("cuda", 0)
 gen_kw, model_kw = WORKLOADS["cfg2"]
+if len(sys.argv) > 1:
+    gen_kw = dict(gen_kw, n_cells=int(sys.argv[1]))
 model = build_model(model_kw, 1234, dev)
 batch = jittered_cubic_cells(seed=1234, device=dev, **gen_kw)
 with torch.no_grad():
@@ -33,4 +35,4 @@ with torch.no_grad():
         g.replay()
     torch.cuda.synchronize()
     graph = (time.perf_counter() - t0) / 20 * 1e3
-print(f"eager {eager:.3f} ms  graph {graph:.3f} ms  max diff {float((out - ref).abs().max()):.3e}")
+print(f"n_cells {gen_kw['n_cells']}: eager {eager:.3f} ms  graph {graph:.3f} ms  max diff {float((out - ref).abs().max()):.3e}")
