@@ -13,19 +13,23 @@ from .inits import glorot, glorot_orthogonal
 
 
 def _normalize_string(s: str) -> str:
-    return s.lower().replace("-", "").replace("_", "").replace(" ", "")
+    return "".join(ch for ch in s.lower() if ch not in "-_ ")
 
 
 def _resolver(query: Any, classes: list, base_cls: type | None = None, return_initialize: bool = True, **kwargs):
+    """Look `query` up among `classes`: a (normalised) name, one of the classes / any subclass of `base_cls`, or — for
+    plain callables such as init functions — the callable itself.  Classes are instantiated with **kwargs unless
+    return_initialize is False.  ValueError for anything else, with the reference's two messages."""
+    make = (lambda c: c(**kwargs)) if return_initialize else (lambda c: c)
     if isinstance(query, str):
-        for cls in classes:
-            if _normalize_string(cls.__name__.lower()) == query:
-                return cls(**kwargs) if return_initialize else cls
+        by_name = {_normalize_string(c.__name__): c for c in reversed(classes)}   # first match wins, as a linear scan
+        if query in by_name:
+            return make(by_name[query])
     elif isinstance(query, type):
-        if query in classes or (base_cls is not None and issubclass(query, base_cls)):
-            return query(**kwargs) if return_initialize else query
+        if any(query is c for c in classes) or (base_cls is not None and issubclass(query, base_cls)):
+            return make(query)
     elif callable(query):
-        if query in classes:
+        if any(query is c for c in classes):
             return query
     else:
         raise ValueError(f"{query} must be str or type or class")
