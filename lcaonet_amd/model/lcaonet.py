@@ -428,17 +428,21 @@ class LCAONet(BaseMPNN):
 
     # --- one graph sharded over several GPUs (lcaonet_amd/shard.py) ---------------------------------------------
     @torch.no_grad()
-    def forward_sharded(self, plan, exchange_fn=None, reduce_fn=None, group=None, fused: bool | None = None):
+    def forward_sharded(self, plan, exchange_fn=None, reduce_fn=None, group=None, fused: bool | None = None,
+                        reverse_fn=None):
         """This rank's part of forward() on a graph partitioned by centre node.  `plan` = shard.make_plans(...)[rank].
         Collectives: L-1 all-gathers of boundary node rows (exchange_fn, default shard.exchange_ghosts over `group`)
         and one all-reduce of the (B, out) per-graph partial sums (reduce_fn).  Returns the global (B, out) result
         (identical on every rank) or ((B, out), forces of the owned nodes)."""
         from .. import shard
 
-        if self.regress_forces and not self.direct_forces:
-            raise NotImplementedError("forward_sharded: autograd forces need a reverse halo exchange, which is not built")
         if self.training:
             raise NotImplementedError("forward_sharded: eval mode only (BatchNorm batch statistics would need a collective)")
+        if self.regress_forces and not self.direct_forces:
+            # F = -dE/dpos of the owned atoms: sharded reverse sweep with L reverse halo exchanges (model/forces.py)
+            from .forces import run_sharded_forces
+
+            return run_sharded_forces(self, plan, group, exchange_fn, reduce_fn, reverse_fn)
         exchange_fn = exchange_fn or (lambda x_own: shard.exchange_ghosts(plan, x_own, group))
         reduce_fn = reduce_fn or (lambda part: shard.reduce_graph_outputs(part, group))
         graph = plan.graph

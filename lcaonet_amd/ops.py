@@ -454,10 +454,13 @@ def triplet_bwd(g_tbw, Ag, gram, uvec_p, src_p, dst_p, in_ptr, in_pos, out_ptr, 
     dev = Ag.device
     all_centres = (n_own == out_ptr.numel() - 1) and e_own == E
     if mfma is None:
-        mfma = V in FUSED_WIDTHS and all_centres
+        mfma = V in FUSED_WIDTHS
     if mfma:
-        g_Ag, g_gram = torch.empty_like(Ag), torch.empty(E, 10, device=dev)
-        g_uq, g_up = torch.empty(E, 3, device=dev), torch.empty(E, 3, device=dev)
+        # every edge is an in-edge of exactly one node: with all nodes as centres every output row is written; with
+        # owned centres only (sharded graph) the rows of the other edges must read as zero
+        new = torch.empty if all_centres else torch.zeros
+        g_Ag, g_gram = new(E, n_l, V, device=dev), new(E, 10, device=dev)
+        g_uq, g_up = new(E, 3, device=dev), new(E, 3, device=dev)
         _call("lcao_triplet_bwd_mfma", _p(g_tbw), _p(Ag), _p(gram), _p(uvec_p), _p(in_ptr), _p(in_pos), _p(out_ptr), n_own,
               E, V, n_l, _p(g_Ag), _p(g_gram), _p(g_uq), _p(g_up), _stream())
         return g_Ag, g_gram, g_uq, g_up
@@ -466,7 +469,7 @@ def triplet_bwd(g_tbw, Ag, gram, uvec_p, src_p, dst_p, in_ptr, in_pos, out_ptr, 
     g_uq = torch.zeros(E, 3, device=dev)
     g_up = torch.zeros(E, 3, device=dev)
     gc = torch.empty(max(n_trip_dense, 1), device=dev, dtype=torch.float32)
-    n_in_total = E if n_own == out_ptr.numel() - 1 else 0   # single GPU: every edge is in exactly one in-list
+    n_in_total = E   # launch-size bound; the kernel reads the exact count in_ptr[n_own] itself
     _call("lcao_triplet_bwd", _p(g_tbw), _p(Ag), _p(gram), _p(uvec_p), _p(src_p), _p(dst_p), _p(in_ptr), _p(in_pos),
           _p(out_ptr), _p(tbase), E, e_own, n_own, n_in_total, V, n_l, _p(g_Ag), _p(g_gram), _p(g_uq), _p(g_up), _p(gc),
           _stream())

@@ -14,6 +14,9 @@ per-layer traffic is one all-gather of boundary node rows (n_boundary x H fp32),
 all-reduce of the (B, out) per-graph partial sums.  xGMI is point to point (7 links/GPU): the all-gather of packed
 boundary rows uses every link at once; nothing the size of x is ever ring-reduced.
 
+Autograd forces (model/forces.py::sharded_force_steps) add the same exchange run backwards: dE/dx of ghost nodes per
+layer and dE/dpos of ghost atoms return to their owners through ONE reduce-scatter of the slot buffer (reverse_exchange).
+
 Local numbering: owned nodes first [0, n_own), ghosts after; edges sorted by centre then have the owned out-edges as a
 prefix [0, e_own) of p-space, so the kernels simply run with smaller counts (triplet / message kernels over n_own,
 e_own; the coefficient kernel over all local edges because ghost->owned edges feed the three-body term).
@@ -136,6 +139,42 @@ def exchange_ghosts(plan: ShardPlan, x_own: Tensor, group=None) -> Tensor:
     if plan.max_send > 0:
         dist.all_gather_into_tensor(recv.view(-1, send.shape[1]), send, group=group)
     return unpack_ghosts(plan, recv)
+
+
+def scatter_ghost_rows(plan: ShardPlan, g_ghost: Tensor) -> Tensor:
+    """(n_ghost, W) rows held for ghost nodes -> the (world * max_send, W) slot buffer of the forward all-gather with
+    those rows at their owners' slots (zero elsewhere): the operand of the reverse collective."""
+    buf = g_ghost.new_zeros((plan.world * plan.max_send, g_ghost.shape[1]))
+    if plan.n_ghost:
+        buf[plan.ghost_flat] = g_ghost          # ghost_flat is injective: one slot per ghost
+    return buf
+
+
+def own_addend(plan: ShardPlan, slots: Tensor) -> Tensor:
+    """(max_send, W) reduced slot rows of THIS rank -> (n_own, W) addend for its owned nodes (zero for interior nodes)."""
+    out = slots.new_zeros((plan.n_own, slots.shape[1]))
+    n_send = plan.send_idx.numel()
+    if n_send:
+        out[plan.send_idx] = slots[:n_send]     # send_idx is injective
+    return out
+
+
+def reverse_exchange(plan: ShardPlan, g_ghost: Tensor, group=None) -> Tensor:
+    """The forward halo all-gather run backwards: every rank contributes what it holds for its ghosts, every owner
+    receives the sum for its boundary nodes — ONE reduce-scatter of the slot buffer (RCCL); gloo has no
+    reduce-scatter, there an all-reduce of the slot buffer is sliced instead."""
+    import torch.distributed as dist
+
+    buf = scatter_ghost_rows(plan, g_ghost)
+    if plan.max_send == 0:
+        return g_ghost.new_zeros((plan.n_own, g_ghost.shape[1]))
+    mine = buf.new_empty((plan.max_send, buf.shape[1]))
+    if dist.get_backend(group) == "gloo":
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        mine.copy_(buf[plan.rank * plan.max_send: (plan.rank + 1) * plan.max_send])
+    else:
+        dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=group)
+    return own_addend(plan, mine)
 
 
 def run_sharded_layers(plan: ShardPlan, x_local: Tensor, n_layers: int, layer_fn, exchange_fn) -> Tensor:

@@ -92,6 +92,40 @@ def test_sharded_layers_match_unsharded_oracle(world):
     assert bool(seen.all())
 
 
+def _reverse_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = shard.make_plans(_graph(), world)[rank]
+        gid = plan.ghost_global.double()
+        g_ghost = torch.stack([(gid + 1) * (rank + 1), gid * 0 + 10.0 ** rank], dim=1).float()
+        ret[rank] = (plan.owned_global.clone(), shard.reverse_exchange(plan, g_ghost).clone())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reverse_exchange_sums_ghost_rows_at_their_owners(world):
+    """shard.reverse_exchange (the halo all-gather run backwards; a reduce-scatter over RCCL, all-reduce + slice over gloo):
+    every owned node receives the sum of the rows the OTHER ranks hold for it as a ghost; interior nodes receive zero."""
+    plans = shard.make_plans(_graph(), world)
+    N = _graph()["z"].numel()
+    want = torch.zeros(N, 2, dtype=torch.float64)
+    for p in plans:
+        want[p.ghost_global, 0] += (p.ghost_global.double() + 1) * (p.rank + 1)
+        want[p.ghost_global, 1] += 10.0 ** p.rank
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reverse_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        owned, got = ret[r]
+        assert got.shape == (owned.numel(), 2)
+        assert torch.allclose(got.double(), want[owned], rtol=1e-6, atol=0)
+    assert float(want.abs().sum()) > 0
+
+
 def test_plan_invariants():
     g = _graph()
     N = g["z"].numel()
