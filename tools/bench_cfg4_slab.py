@@ -2,7 +2,7 @@
 (cutoff 6.0, <= 32 nearest neighbours) on the device, partition it into 8 slabs (shard.make_plans) and time rank r's
 forward_sharded — its owned slab plus the replicated halo edges — with the boundary exchange replaced by a local stand-in
 (no other ranks exist here; the exchange itself is one all-gather of the printed size per interaction).
-usage: python tools/bench_cfg4_slab.py [rank] [steps]"""
+usage: python tools/bench_cfg4_slab.py [rank] [steps] [forces]   (forces: also time energy + autograd forces of the owned atoms)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -50,3 +50,18 @@ print(f"rank {rank}: {ms:.1f} ms per forward for e_own={plan.e_own} owned edges 
 print(f"exchange per interaction: all-gather of {plan.max_send} boundary rows x {H} fp32 = {plan.max_send * H * 4 / 1e6:.1f} MB per rank "
       f"({calls[0] // steps} exchanges per forward); peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 print(f"whole crystal on 8 such ranks (projection, not measured): {E / ms * 1e3 / 1e6:.0f} M edges/s")
+if len(sys.argv) > 3 and sys.argv[3] == "forces":
+    fm = build_model(dict(WORKLOADS["cfg4-1of8"][1], regress_forces=True, direct_forces=False), 1234, dev)
+    kw = dict(exchange_fn=fake_exchange, reduce_fn=lambda part: part,
+              reverse_fn=lambda gq: gq.new_zeros(plan.n_own, gq.shape[1]))
+    with torch.no_grad():
+        out, f = fm.forward_sharded(plan, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, f = fm.forward_sharded(plan, **kw)
+        torch.cuda.synchronize()
+    msf = (time.perf_counter() - t0) / steps * 1e3
+    print(f"rank {rank}: energy + forces of the {plan.n_own} owned atoms {msf:.1f} ms = {plan.e_own / msf * 1e3 / 1e6:.1f} M owned edges/s "
+          f"per GPU; 3 reverse exchanges (reduce-scatter of {plan.world * plan.max_send * H * 4 / 1e6:.0f} MB slot buffers); "
+          f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
