@@ -220,7 +220,8 @@ def forward_with_autograd_forces(model, graph, tables=None):
     m_out = (ctx.out_ptr[1:] - ctx.out_ptr[:-1]).long()
     prod = m_in * m_out
     tbase = (torch.cumsum(prod, 0) - prod).contiguous()
-    n_trip_dense = int(prod.sum().item())
+    # only the any-V fallback of the three-body backward needs the scratch size (a host sync); the MFMA kernel does not
+    n_trip_dense = int(prod.sum().item()) if model.emb_size_conv not in ops.FUSED_WIDTHS else 1
 
     forces = []
     for i in range(model.out_size):
