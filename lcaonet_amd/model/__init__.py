@@ -1,3 +1,4 @@
+from .capture import CapturedForward
 from .lcaonet import LCAONet
 
-__all__ = ["LCAONet"]
+__all__ = ["LCAONet", "CapturedForward"]

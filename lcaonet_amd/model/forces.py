@@ -164,7 +164,7 @@ def _check_supported(model, have_tables: bool = False):
 
 
 @torch.no_grad()
-def forward_with_autograd_forces(model, graph, tables=None):
+def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
     """Returns (out (B, out_size), force) with force = -d(sum_b out[b, i])/dpos: (N, 3) for out_size == 1,
     (N, out_size, 3) otherwise — the shapes of lcaonet.py:310-317.
     tables = (x_tab (max_z+1, H), cst_pair, zdim): embedding tables supplied by the caller (model/train.py: train-mode
@@ -178,7 +178,7 @@ def forward_with_autograd_forces(model, graph, tables=None):
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(pos, "graph.pos")
     N = z.size(0)
-    ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], N)
+    ctx = ctx if ctx is not None else EdgeContext.build(graph[GraphKeys.Edge_idx], N)
     graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
     dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
     uvec_p = ctx.uvec_p(uvec)
@@ -208,7 +208,7 @@ def forward_with_autograd_forces(model, graph, tables=None):
     red = "sum" if model.out_layer.is_extensive else "mean"
     if batch_idx is not None:
         out = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce=red)
-        cnt = torch.bincount(batch_idx, minlength=out.shape[0]).clamp(min=1).to(prop.dtype)
+        cnt = scatter(torch.ones(N, 1, device=prop.device), batch_idx, dim=0, dim_size=out.shape[0])[:, 0].clamp(min=1)
         node_scale = torch.ones(N, device=prop.device) if red == "sum" else (1.0 / cnt)[batch_idx]
     else:
         out = prop.sum(0, keepdim=True) if red == "sum" else prop.mean(0, keepdim=True)

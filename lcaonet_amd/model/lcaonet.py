@@ -58,11 +58,14 @@ class EdgeContext:
     src_o: Tensor      # (E)   idx_s as int32, orig order
     dst_o: Tensor      # (E)   idx_t as int32, orig order
     _uvec_p: Tensor | None = None
+    _uvec_src: Tensor | None = None
 
     def uvec_p(self, uvec: Tensor) -> Tensor:
-        """Unit vectors permuted to p-space (computed once per forward, shared by the layers)."""
-        if self._uvec_p is None:
+        """Unit vectors permuted to p-space (computed once per forward and shared by the layers; a context that
+        outlives a forward — model/capture.py — sees a new `uvec` tensor next time and permutes again)."""
+        if self._uvec_p is None or self._uvec_src is not uvec:
             self._uvec_p = ops.gather_rows(uvec, self.order)
+            self._uvec_src = uvec
         return self._uvec_p
 
     @staticmethod
@@ -492,7 +495,7 @@ class LCAONet(BaseMPNN):
     # --- forward ------------------------------------------------------------------------------------------
     def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
                 trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
-                differentiable: bool | None = None, precision: str = "fp32"):
+                differentiable: bool | None = None, precision: str = "fp32", edge_context: EdgeContext | None = None):
         """graph: PyG-Batch-like object with z, pos, edge_index [centre, neighbour], edge_shift, lattice and
         optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
 
@@ -510,7 +513,8 @@ class LCAONet(BaseMPNN):
             return forward_differentiable(self, graph)
         if precision not in ("fp32", "bf16x3"):
             raise ValueError(f"precision={precision!r}: expected 'fp32' or 'bf16x3'")
-        return self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision)
+        return self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision,
+                                       edge_context)
 
     @torch.no_grad()
     def pair_valence_mask(self, zdim: int) -> Tensor:
@@ -520,12 +524,12 @@ class LCAONet(BaseMPNN):
 
     def _forward_inference(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
                            trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
-                           precision: str = "fp32"):
+                           precision: str = "fp32", edge_context: EdgeContext | None = None):
         if self.regress_forces and not self.direct_forces:
             # F = -dE/dpos (lcaonet.py:310-317): species-pair forward + hand-written reverse sweep (model/forces.py)
             from .forces import forward_with_autograd_forces
 
-            return forward_with_autograd_forces(self, graph)
+            return forward_with_autograd_forces(self, graph, ctx=edge_context)
         batch_idx = graph.get(GraphKeys.Batch_idx)
         z = graph[GraphKeys.Z]
         pos = graph[GraphKeys.Pos]
@@ -534,7 +538,9 @@ class LCAONet(BaseMPNN):
         ops._dev(pos, "graph.pos")
         N = z.size(0)
 
-        ctx = EdgeContext.build(edge_index, N)
+        # edge_context: the index structures of this edge list built earlier (EdgeContext.build) — they do not depend on
+        # positions, so a caller that keeps the edge list (model/capture.py) builds them once
+        ctx = edge_context if edge_context is not None else EdgeContext.build(edge_index, N)
         graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
         dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
         if materialize_triplets:

@@ -824,6 +824,32 @@ def test_force_training_central_difference_vs_oracle_double_backward(dev, traini
     print(f"central-difference force training: worst parameter-gradient deviation {worst:.2e} over {checked} tensors")
 
 
+@pytest.mark.parametrize("forces", [False, True])
+def test_captured_forward_replays_with_new_positions(dev, forces):
+    """model/capture.py: one whole forward (and the autograd-force sweep) captured as a HIP graph and replayed with moved
+    atoms on the same edge list equals the eager call on those positions, bit for bit."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import CapturedForward
+    kw = dict(emb_size=64, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=4.0)
+    if forces:
+        kw.update(regress_forces=True, direct_forces=False)
+    m, _ = _random_model(dev, 73, **kw)
+    g = random_periodic_cells(2, 12, 6.0, 0.9 * 4.0, seed=8).to(dev)          # list built with a skin (0.9 rc)
+    step = CapturedForward(m, g)
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        new_pos = g["pos"] + 0.05 * torch.randn(g["pos"].shape, generator=gen).to(dev)
+        got = step(new_pos)
+        from lcaonet_amd.data.graph import Data
+        moved = Data(**{k: g[k] for k in ("z", "edge_index", "edge_shift", "lattice", "batch")}, pos=new_pos)
+        want = m(moved)
+        if forces:
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+            assert float(want[1].abs().max()) > 0
+        else:
+            assert torch.equal(got, want)
+
+
 def test_segment_sum_kernels(dev):
     """lcao_segment_sum (+ optional row-wise multiplier) and lcao_segment_sum_gather against index_add in fp64: the 16-byte
     kernels (widths 32 / 64 / 128 / 256), the scalar kernels (3, 20, 1024), empty and very long segments; bitwise
