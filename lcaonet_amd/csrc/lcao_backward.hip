@@ -462,7 +462,7 @@ __global__ void k_pair_contract_bwd(const float* __restrict__ Tf, const float* _
 }
 
 // fast form for V in {32, 64, 128}: 16 lanes per edge (4 edges per wave), float4 channel chunks, DPP row reductions
-template <int V, int NL>
+template <int V, int NL, int DC>   // DC = 8: n_orb <= 8, the table block of the edge is kept in registers between the two passes
 __global__ __launch_bounds__(256) void k_pair_contract_bwd16(
     const float* __restrict__ Tf, const float* __restrict__ rb, const int32_t* __restrict__ order,
     const int32_t* __restrict__ l_of_d, const int64_t* __restrict__ z, const int32_t* __restrict__ src_p,
@@ -486,16 +486,33 @@ __global__ __launch_bounds__(256) void k_pair_contract_bwd16(
     for (int l = 0; l < NL; ++l)
 #pragma unroll
       for (int c = 0; c < NC; ++c) a[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int d = 0; d < D; ++d) {
-      const float w = rb[e * D + d];
-      const int l = l_of_d[d];
+    f32x4 tc[DC > 0 ? DC : 1][NC];
+    if constexpr (DC > 0) {
 #pragma unroll
-      for (int ll = 0; ll < NL; ++ll)
-        if (l == ll) {
+      for (int d = 0; d < DC; ++d) {
+        if (d < D) {
+          const float w = rb[e * D + d];
+          const int l = l_of_d[d];
 #pragma unroll
-          for (int c = 0; c < NC; ++c)
-            if ((64 * c + 4 * sub) < V) a[ll][c] += w * *(const f32x4*)(t + d * V + 64 * c);
+          for (int c = 0; c < NC; ++c) {
+            tc[d][c] = (64 * c + 4 * sub) < V ? *(const f32x4*)(t + d * V + 64 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ll = 0; ll < NL; ++ll) a[ll][c] += (l == ll ? w : 0.f) * tc[d][c];
+          }
         }
+      }
+    } else {
+      for (int d = 0; d < D; ++d) {
+        const float w = rb[e * D + d];
+        const int l = l_of_d[d];
+#pragma unroll
+        for (int ll = 0; ll < NL; ++ll)
+          if (l == ll) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if ((64 * c + 4 * sub) < V) a[ll][c] += w * *(const f32x4*)(t + d * V + 64 * c);
+          }
+      }
     }
     float gG[10];
 #pragma unroll
@@ -527,21 +544,40 @@ __global__ __launch_bounds__(256) void k_pair_contract_bwd16(
       }
       if (valid && chv) *(f32x4*)(g_gate_part + p * V + off) = gpart;
     }
-    for (int d = 0; d < D; ++d) {
-      const int l = l_of_d[d];
-      float acc = 0.f;
+    if constexpr (DC > 0) {
 #pragma unroll
-      for (int ll = 0; ll < NL; ++ll)
-        if (l == ll) {
+      for (int d = 0; d < DC; ++d) {
+        if (d < D) {
+          const int l = l_of_d[d];
+          float acc = 0.f;
 #pragma unroll
-          for (int c = 0; c < NC; ++c)
-            if ((64 * c + 4 * sub) < V) {
-              const f32x4 tv = *(const f32x4*)(t + d * V + 64 * c);
-              acc += gA[ll][c][0] * tv[0] + gA[ll][c][1] * tv[1] + gA[ll][c][2] * tv[2] + gA[ll][c][3] * tv[3];
-            }
+          for (int c = 0; c < NC; ++c) {
+            f32x4 gsel = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ll = 0; ll < NL; ++ll) gsel = (l == ll) ? gA[ll][c] : gsel;
+            acc += gsel[0] * tc[d][c][0] + gsel[1] * tc[d][c][1] + gsel[2] * tc[d][c][2] + gsel[3] * tc[d][c][3];
+          }
+          acc = lcao_row16_sum(acc);
+          if (valid && sub == 0) g_rb[e * D + d] += acc;
         }
-      acc = lcao_row16_sum(acc);
-      if (valid && sub == 0) g_rb[e * D + d] += acc;
+      }
+    } else {
+      for (int d = 0; d < D; ++d) {
+        const int l = l_of_d[d];
+        float acc = 0.f;
+#pragma unroll
+        for (int ll = 0; ll < NL; ++ll)
+          if (l == ll) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if ((64 * c + 4 * sub) < V) {
+                const f32x4 tv = *(const f32x4*)(t + d * V + 64 * c);
+                acc += gA[ll][c][0] * tv[0] + gA[ll][c][1] * tv[1] + gA[ll][c][2] * tv[2] + gA[ll][c][3] * tv[3];
+              }
+          }
+        acc = lcao_row16_sum(acc);
+        if (valid && sub == 0) g_rb[e * D + d] += acc;
+      }
     }
   }
 }
@@ -562,8 +598,14 @@ extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const in
   hipStream_t st = (hipStream_t)stream;
 #define PB16(V_, NL_)                                                                                                  \
   if (V == V_ && n_l == NL_) {                                                                                         \
-    hipLaunchKernelGGL((k_pair_contract_bwd16<V_, NL_>), dim3(lcao_blocks(n_edges, 16, 65536)), block, 0, st, Tf, rb, order, \
-                       l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, n_edges, e_own, n_orb, zdim, g_rb, g_gate_part, g_A_out); \
+    if (n_orb <= 8)                                                                                                    \
+      hipLaunchKernelGGL((k_pair_contract_bwd16<V_, NL_, 8>), dim3(lcao_blocks(n_edges, 16, 65536)), block, 0, st, Tf, rb,  \
+                         order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, n_edges, e_own, n_orb, zdim, g_rb,    \
+                         g_gate_part, g_A_out);                                                                        \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_pair_contract_bwd16<V_, NL_, 0>), dim3(lcao_blocks(n_edges, 16, 65536)), block, 0, st, Tf, rb,  \
+                         order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, n_edges, e_own, n_orb, zdim, g_rb,    \
+                         g_gate_part, g_A_out);                                                                        \
     return lcao_launch_status();                                                                                       \
   }
 #define PB16V(V_) PB16(V_, 1) PB16(V_, 2) PB16(V_, 3) PB16(V_, 4)
