@@ -834,19 +834,24 @@ __global__ __launch_bounds__(256) void k_message_bwd_mfma(
         if (g_pre2_out) *(f32x4v*)(g_pre2_out + p * V + 16 * m + 4 * q) = gp2[m];
       }
     }
+    // the node rows of the epilogue (pre1 = Ps[s] + Pt[t]) are requested before the GEMM and land under it
+    f32x4v x1[MT];
+    {
+      const float* ps = Ps + (int64_t)s * V + 4 * q;
+      const float* pt = Pt + (int64_t)t * V + 4 * q;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) x1[m] = *(const f32x4v*)(ps + 16 * m) + *(const f32x4v*)(pt + 16 * m);
+    }
     f32x4v gh[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) gh[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
     mfma_layer<MT, MT>(lds, V + 4, r, q, gp2, gh);
     if (valid) {
-      const float* ps = Ps + (int64_t)s * V + 4 * q;
-      const float* pt = Pt + (int64_t)t * V + 4 * q;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const f32x4v x1 = *(const f32x4v*)(ps + 16 * m) + *(const f32x4v*)(pt + 16 * m);
         f32x4v o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = gh[m][j] * lcao_silu_grad(x1[j]);
+        for (int j = 0; j < 4; ++j) o[j] = gh[m][j] * lcao_silu_grad(x1[m][j]);
         *(f32x4v*)(g_pre1 + p * V + 16 * m + 4 * q) = o;
       }
     }
