@@ -94,6 +94,10 @@ def _call(name: str, *args) -> None:
 
 def build_csr(idx_s: Tensor, idx_t: Tensor, n_nodes: int) -> dict:
     """All int32 index structures of one forward in one C-ABI call (no host sync, no torch sort)."""
+    if torch.cuda.is_current_stream_capturing():
+        # rocPRIM's device radix sort keeps host-side state per call; frozen into a HIP graph it faulted on replay
+        raise _lib.LcaoHipError("lcao_build_csr cannot be captured into a HIP graph: build the EdgeContext before the "
+                                "capture and pass it as edge_context= (lcaonet_amd.model.CapturedForward does)")
     idx_s, idx_t = _i64(idx_s, "edge_index[0]"), _i64(idx_t, "edge_index[1]")
     E, dev = idx_s.numel(), idx_s.device
     i32 = lambda n: torch.empty(n, device=dev, dtype=torch.int32)
