@@ -850,6 +850,37 @@ def test_captured_forward_replays_with_new_positions(dev, forces):
             assert torch.equal(got, want)
 
 
+def test_md_energy_conservation_with_captured_forces(dev):
+    """A size-independent property of the force path: velocity-Verlet dynamics driven by the replayed HIP graph
+    (CapturedForward, fixed edge list with a skin) conserves kinetic + potential energy while the potential energy itself
+    changes by orders of magnitude more — forces that were not the exact gradient of the energy would show up as drift."""
+    from lcaonet_amd.data.synthetic import jittered_cubic_cells
+    from lcaonet_amd.model import CapturedForward, LCAONet
+    torch.manual_seed(3)
+    m = LCAONet(emb_size=64, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=5.0, regress_forces=True,
+                direct_forces=False).to(dev).eval()
+    g = jittered_cubic_cells(1, n_side=3, a=3.0, sigma=0.03, cutoff_graph=4.7, seed=5, device=dev)
+    step = CapturedForward(m, g)
+    x = g["pos"].clone()
+    v = (0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(1))).to(dev)
+    v -= v.mean(0)
+    dt = 0.02
+    e, f = step(x)
+    pe0, f = float(e.sum()), f.clone()
+    e_tot0 = pe0 + 0.5 * float((v * v).sum())
+    drift = pe_change = 0.0
+    for _ in range(100):
+        v = v + 0.5 * dt * f
+        x = x + dt * v
+        e, f = step(x)
+        pe, f = float(e.sum()), f.clone()
+        v = v + 0.5 * dt * f
+        drift = max(drift, abs(pe + 0.5 * float((v * v).sum()) - e_tot0))
+        pe_change = max(pe_change, abs(pe - pe0))
+    assert pe_change > 1e-3, pe_change
+    assert drift < 1e-5 and drift < 2e-2 * pe_change, (drift, pe_change)
+
+
 def test_segment_sum_kernels(dev):
     """lcao_segment_sum (+ optional row-wise multiplier) and lcao_segment_sum_gather against index_add in fp64: the 16-byte
     kernels (widths 32 / 64 / 128 / 256), the scalar kernels (3, 20, 1024), empty and very long segments; bitwise
