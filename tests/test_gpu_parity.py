@@ -455,6 +455,20 @@ def test_pair_table_mode_vs_oracle_and_edge_mode(dev, width, heads, valence):
     assert relerr(tr["x2"], wtr["x2"]) <= TOL
     assert relerr(got, want) <= TOL
     assert relerr(got, m(g.to(dev))) <= 2e-6
+    if width in (32, 64, 128) and not valence:
+        # lcao_pair_contract_visit: the same contraction walking the edges sorted by species pair — bitwise equal
+        from lcaonet_amd import ops
+        from lcaonet_amd.model.lcaonet import EdgeContext
+        gd = g.to(dev)
+        ctx = EdgeContext.build(gd["edge_index"], gd["z"].numel())
+        zz = gd["z"]
+        Tf = torch.randn(37 * 37, 8, width, device=dev)
+        rbx = torch.randn(ctx.n_edges, 8, device=dev)
+        gate = torch.rand(zz.numel(), width, device=dev)
+        visit = torch.argsort(zz[ctx.src_p.long()] * 37 + zz[ctx.dst_p.long()], stable=True).to(torch.int32)
+        a = ops.pair_contract(Tf, rbx, ctx.order, m.shbf.l_of_d, zz, ctx.src_p, ctx.dst_p, gate, m.n_l, 37)
+        b = ops.pair_contract(Tf, rbx, ctx.order, m.shbf.l_of_d, zz, ctx.src_p, ctx.dst_p, gate, m.n_l, 37, visit=visit)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
     # the pair table really is what the per-edge tensor holds
     z = g["z"]; idx_s, idx_t = g["edge_index"]
     assert relerr(tr["cst"][(z[idx_s] * 37 + z[idx_t]).to(dev)][:64], wtr["cst"][:64]) <= TOL
