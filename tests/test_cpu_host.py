@@ -114,6 +114,42 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"invalid" in _lib.load().lcao_error_string(-1)
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype in include/lcaonet_hip.h against lcaonet_amd/_lib.py::SIGNATURES: same number of parameters and the
+    same C type class per position (pointer / int64_t / int / float / size_t) — an ABI mismatch would otherwise only show
+    up as a corrupted argument on the GPU."""
+    from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+    hdr = open(os.path.join(REPO, "include", "lcaonet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = re.findall(r"\b(lcao_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 40
+
+    def kind(param: str):
+        param = " ".join(param.split())
+        if "*" in param:
+            return c_void_p
+        if param.startswith("int64_t"):
+            return c_int64
+        if param.startswith("size_t"):
+            return c_size_t
+        if param.startswith("float"):
+            return c_float
+        if param.startswith("int"):
+            return c_int
+        raise AssertionError(f"unrecognised parameter {param!r}")
+
+    checked = 0
+    for name, params in protos:
+        params = params.strip()
+        want = [] if params in ("", "void") else [kind(p) for p in params.split(",")]
+        got = list(_lib.SIGNATURES[name])
+        assert len(got) == len(want), (name, len(got), len(want))
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g is w, (name, i, g, w)
+        checked += 1
+    assert checked == len(_lib.SIGNATURES)
+
+
 def test_no_cpu_fallback():
     """Off-GPU the product path raises instead of computing on the host."""
     from lcaonet_amd import ops
