@@ -218,7 +218,7 @@ class LCAOInteraction(nn.Module):
     def _fusable(self, C: int) -> bool:
         V = self.emb_size_conv
         acts_silu = all(type(m) is nn.SiLU for m in (self.f_coeffs[1], self.f_coeffs[3], self.f_node[1], self.f_node[3]))
-        return acts_silu and V in ops.FUSED_WIDTHS and C == V
+        return acts_silu and (C, V) in ops.FUSED_COEFF_SHAPES
 
     @torch.no_grad()
     def forward_fused(self, x: Tensor, cst: Tensor, valence_ed: Tensor | None, rb: Tensor, uvec: Tensor,
@@ -261,7 +261,7 @@ class LCAOInteraction(nn.Module):
                 Ag, gram, B = pc(Tf)
                 Bv = None
             tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
-        elif fused and precision == "bf16x3" and not self.add_valence:
+        elif fused and precision == "bf16x3" and not self.add_valence and cst.shape[-1] == V:
             # BASELINE config 3: bf16 MFMA on the per-edge coefficient GEMMs, operands split into two bf16 terms
             Ag, gram, B, Bv = ops.coeff_mlp_contract_bf16x3(
                 cst, rb, ctx.order, l_of_d, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(), n_l,

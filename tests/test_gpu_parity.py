@@ -369,6 +369,24 @@ def test_sharded_forward_hip_matches_unsharded(dev, world, cells):
     assert relerr(total, full) <= 2e-6
 
 
+@pytest.mark.parametrize("C,V", [(64, 128), (128, 64)])
+def test_fused_path_mixed_coeff_and_conv_widths(dev, C, V):
+    """emb_size_coeff != emb_size_conv on the fused MFMA kernels (lcao_coeff_mlp_contract<C, V>) against the oracle."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=32, emb_size_coeff=C, emb_size_conv=V, n_interaction=2, cutoff=5.0)
+    m, sd = _random_model(dev, 640 + C, **kw)
+    assert m.int_layers[0]._fusable(C)
+    g = random_periodic_cells(3, 14, 6.2, 0.99 * 5.0, seed=C)
+    want, wtr = _oracle_run(sd, kw, g.to_dict())
+    tr = {}
+    got = m(g.to(dev), trace=tr)
+    order = tr["order"].long().cpu()
+    assert relerr(tr["three_body_w2"], wtr["three_body_w2"][order]) <= TOL
+    assert relerr(got, want) <= TOL
+    assert relerr(m(g.to(dev), fused=False), want) <= TOL
+    assert relerr(m(g.to(dev), precision="bf16x3"), want) <= 2e-5      # coefficient kernel stays fp32 for C != V
+
+
 def _lockstep_sharded_forces(model, plans):
     """Run model/forces.py::sharded_force_steps for every rank of `plans` in lock step on one device, serving their
     communication requests jointly (what shard.exchange_ghosts / reduce_graph_outputs / reverse_exchange do over RCCL)."""
