@@ -699,7 +699,7 @@ extern "C" int lcao_geometry_bwd(const float* dist, const float* uvec, const flo
 // ---------------------------------------------------------------------------------------------------
 // gradient of the species-pair table (training):  A[p,l,:] = sum_{d in l} rb[e,d] Tf[pair(p),d,:]  =>
 //   g_Tf[pair,d,:] = sum_{p: pair(p) = pair} rb[e,d] g_A[p,l(d),:]
-// Edges are visited sorted by pair id (perm); every pair's list is cut into chunks of <= 256 edges (chunk_ptr over the
+// Edges are visited sorted by pair id (perm); every pair's list is cut into chunks of <= 64 edges (chunk_ptr over the
 // sorted list, chunks never span pairs); one wave per chunk writes a partial (D, V) table; the caller sums each pair's
 // partials in order (lcao_segment_sum) — deterministic, no atomics.
 // ---------------------------------------------------------------------------------------------------
@@ -720,26 +720,38 @@ __global__ void k_pair_table_grad(const float* __restrict__ g_A, const float* __
       for (int dd = 0; dd < DMAX; ++dd)
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[dd][r] = 0.f;
-      for (int i = i0; i < i1; ++i) {
-        const int p = perm[i];
-        const int64_t e = order ? order[p] : p;
-        float ga[4][R];
+      // U edges per iteration: their index loads and their g_A rows are independent and stay in flight together
+      constexpr int U = 4;
+      for (int i = i0; i < i1; i += U) {
+        int pu[U];
+        int64_t eu[U];
 #pragma unroll
-        for (int l = 0; l < 4; ++l)
+        for (int u = 0; u < U; ++u) {
+          pu[u] = perm[min(i + u, i1 - 1)];
+          eu[u] = order ? order[pu[u]] : pu[u];
+        }
+        float ga[U][4][R];
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int ch = lane + 64 * r;
-            ga[l][r] = (l < NL && ch < V) ? g_A[((int64_t)p * NL + l) * V + ch] : 0.f;
-          }
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int dd = 0; dd < DMAX; ++dd) {
-          const int d = d0 + dd;
-          if (d < D) {
-            const float w = rb[e * D + d];
-            const int l = l_of_d[d];
+          for (int l = 0; l < 4; ++l)
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-              acc[dd][r] += w * (l == 0 ? ga[0][r] : (l == 1 ? ga[1][r] : (l == 2 ? ga[2][r] : ga[3][r])));
+            for (int r = 0; r < R; ++r) {
+              const int ch = lane + 64 * r;
+              ga[u][l][r] = (l < NL && ch < V && (i + u) < i1) ? g_A[((int64_t)pu[u] * NL + l) * V + ch] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {   // rows are added in list order: the sum is the same as one edge at a time
+#pragma unroll
+          for (int dd = 0; dd < DMAX; ++dd) {
+            const int d = d0 + dd;
+            if (d < D) {
+              const float w = (i + u) < i1 ? rb[eu[u] * D + d] : 0.f;
+              const int l = l_of_d[d];
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                acc[dd][r] += w * (l == 0 ? ga[u][0][r] : (l == 1 ? ga[u][1][r] : (l == 2 ? ga[u][2][r] : ga[u][3][r])));
+            }
           }
         }
       }

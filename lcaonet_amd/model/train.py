@@ -115,7 +115,7 @@ class _Geom:
         self.order_z = torch.argsort(z, stable=True)
         self.ptr_z = csr_ptr(z[self.order_z], model.emb_layer.max_z + 1)
 
-    def pair_lists(self, pair: Tensor, zd: int, chunk: int = 256):
+    def pair_lists(self, pair: Tensor, zd: int, chunk: int = 64):
         """p-space edges sorted by species pair, cut into chunks of <= `chunk` edges that never span two pairs."""
         ctx = self.ctx
         pair_p = pair[ctx.order.long()]
