@@ -1500,55 +1500,62 @@ extern "C" int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const 
 // the epilogue undoes — so operands come straight from global memory as float4, no LDS, no transposition.  Chunk
 // partials are summed in a fixed order by a second kernel (deterministic, no atomics).
 // ===================================================================================================
-#define LCAO_WGRAD_CHUNKS 512
+#define LCAO_WGRAD_CHUNKS 2048
 
+template <int MB>   // a wave owns a (64 MB) x 64 block of dW: MB = 2 halves the X loads per MFMA when M % 128 == 0
 __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__ G, const float* __restrict__ X,
                                                        int64_t E, int M, int K, int n_chunks,
                                                        float* __restrict__ partial) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int kb = K >> 6, n_blocks = (M >> 6) * kb;
-  const int block = blockIdx.y * 4 + wave;
-  if (block >= n_blocks) return;
+  const int kb = K >> 6, n_blocks = (M / (64 * MB)) * kb;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;          // one (chunk, block) unit per wave
+  const int chunk = (int)(gw / n_blocks), block = (int)(gw - (int64_t)chunk * n_blocks);
+  if (chunk >= n_chunks) return;
   const int bm = block / kb, bk = block - bm * kb;
   const int64_t rows = ((E + n_chunks - 1) / n_chunks + 3) & ~int64_t(3);
-  const int64_t r0 = blockIdx.x * rows, r1 = min(r0 + rows, E);
-  f32x4v acc[4][4];
+  const int64_t r0 = chunk * rows, r1 = min(r0 + rows, E);
+  f32x4v acc[4 * MB][4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4 * MB; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  const float* gp = G + 64 * bm + 4 * i;
+  const float* gp = G + 64 * MB * bm + 4 * i;
   const float* xp = X + 64 * bk + 4 * i;
   const f32x4v zero = f32x4v{0.f, 0.f, 0.f, 0.f};
   const int n_steps = (int)((r1 - r0 + 3) >> 2);
-  for (int s0 = 0; s0 < n_steps; s0 += 4) {   // 4 k-steps (16 rows) per iteration: 8 independent 16-B loads in flight
-    f32x4v g[4], x[4];
+  for (int s0 = 0; s0 < n_steps; s0 += 4) {   // 4 k-steps (16 rows) per iteration: 4 (1 + MB) independent 16-B loads in flight
+    f32x4v g[4][MB], x[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t e = r0 + 4 * (int64_t)(s0 + u) + kq;
       const bool ok = e < r1;
-      g[u] = ok ? *(const f32x4v*)(gp + e * M) : zero;
+#pragma unroll
+      for (int h = 0; h < MB; ++h) g[u][h] = ok ? *(const f32x4v*)(gp + e * M + 64 * h) : zero;
       x[u] = ok ? *(const f32x4v*)(xp + e * K) : zero;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int h = 0; h < MB; ++h)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = MFMA16(g[u][a], x[u][b], acc[a][b]);
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[4 * h + a][b] = MFMA16(g[u][h][a], x[u][b], acc[4 * h + a][b]);
   }
-  // acc[a][b] reg r, lane (i, kq): row index 4*kq + r of feature tile a  <->  m = 64 bm + 4 (4 kq + r) + a;  column i of
-  // tile b <-> k = 64 bk + 4 i + b.   The four b's of a lane are 16 contiguous bytes.
-  float* out = partial + (int64_t)blockIdx.x * M * K;
+  // acc[4h + a][b] reg r, lane (i, kq): row index 4*kq + r of feature tile (h, a)  <->  m = 64 (MB bm + h) + 4 (4 kq + r) + a;
+  // column i of tile b <-> k = 64 bk + 4 i + b.   The four b's of a lane are 16 contiguous bytes.
+  float* out = partial + (int64_t)chunk * M * K;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int h = 0; h < MB; ++h)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = 64 * bm + 4 * (4 * kq + r) + a;
-      const f32x4v v = f32x4v{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
-      *(f32x4v*)(out + (int64_t)m * K + 64 * bk + 4 * i) = v;
-    }
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 64 * (MB * bm + h) + 4 * (4 * kq + r) + a;
+        const f32x4v v = f32x4v{acc[4 * h + a][0][r], acc[4 * h + a][1][r], acc[4 * h + a][2][r], acc[4 * h + a][3][r]};
+        *(f32x4v*)(out + (int64_t)m * K + 64 * bk + 4 * i) = v;
+      }
 }
 
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int64_t mk, float* __restrict__ dW) {
@@ -1566,16 +1573,22 @@ __global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, 
   *(f32x4v*)(dW + j) = (s0 + s1) + (s2 + s3);
 }
 
-static int wgrad_chunks(int64_t E) {
-  int64_t c = (E + 255) / 256;   // at least 256 rows per chunk
+static bool wgrad_wide(int M) { return M % 128 == 0 && M >= 256; }   // 128 x 64 blocks per wave pay off from M = 256
+static int wgrad_blocks(int M, int K) { return (wgrad_wide(M) ? M / 128 : M / 64) * (K / 64); }
+
+// number of row chunks: ~2048 (chunk, block) wave units, at least 256 rows per chunk
+static int wgrad_chunks(int64_t E, int M, int K) {
+  int64_t c = 2048 / wgrad_blocks(M, K);
   if (c > LCAO_WGRAD_CHUNKS) c = LCAO_WGRAD_CHUNKS;
+  const int64_t by_rows = (E + 255) / 256;
+  if (c > by_rows) c = by_rows;
   if (c < 1) c = 1;
   return (int)c;
 }
 
 extern "C" size_t lcao_wgrad_workspace_bytes(int64_t n_rows, int M, int K) {
-  if (n_rows <= 0 || M <= 0 || K <= 0) return 0;
-  return (size_t)wgrad_chunks(n_rows) * M * K * sizeof(float);
+  if (n_rows <= 0 || M <= 0 || K <= 0 || M % 64 || K % 64) return 0;
+  return (size_t)wgrad_chunks(n_rows, M, K) * M * K * sizeof(float);
 }
 
 extern "C" int lcao_wgrad(const float* G, const float* X, int64_t n_rows, int M, int K, float* dW, void* workspace,
@@ -1591,11 +1604,13 @@ extern "C" int lcao_wgrad(const float* G, const float* X, int64_t n_rows, int M,
   }
   LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(X); LCAO_CHECK_PTR(workspace);
   if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) % 16) return LCAO_ERR_INVALID;
-  const int chunks = wgrad_chunks(n_rows);
+  const int chunks = wgrad_chunks(n_rows, M, K);
   if (ws_bytes < (size_t)chunks * M * K * sizeof(float)) return LCAO_ERR_INVALID;
-  const int n_blocks = (M / 64) * (K / 64);
-  hipLaunchKernelGGL(k_wgrad_partial, dim3(chunks, (n_blocks + 3) / 4), dim3(256), 0, st, G, X, n_rows, M, K, chunks,
-                     (float*)workspace);
+  const unsigned groups = (unsigned)(((int64_t)chunks * wgrad_blocks(M, K) + 3) / 4);
+  if (wgrad_wide(M))
+    hipLaunchKernelGGL(k_wgrad_partial<2>, dim3(groups), dim3(256), 0, st, G, X, n_rows, M, K, chunks, (float*)workspace);
+  else
+    hipLaunchKernelGGL(k_wgrad_partial<1>, dim3(groups), dim3(256), 0, st, G, X, n_rows, M, K, chunks, (float*)workspace);
   const int64_t mk = (int64_t)M * K;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(lcao_blocks(mk / 4, 256)), dim3(256), 0, st, (const float*)workspace, chunks, mk,
                      dW);
