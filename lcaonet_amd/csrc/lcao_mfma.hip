@@ -1524,10 +1524,11 @@ __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__
   const float* xp = X + 64 * bk + 4 * i;
   const f32x4v zero = f32x4v{0.f, 0.f, 0.f, 0.f};
   const int n_steps = (int)((r1 - r0 + 3) >> 2);
-  for (int s0 = 0; s0 < n_steps; s0 += 4) {   // 4 k-steps (16 rows) per iteration: 4 (1 + MB) independent 16-B loads in flight
-    f32x4v g[4][MB], x[4];
+  constexpr int U = MB == 1 ? 8 : 4;          // k-steps per iteration: U (1 + MB) independent 16-B loads in flight
+  for (int s0 = 0; s0 < n_steps; s0 += U) {
+    f32x4v g[U][MB], x[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t e = r0 + 4 * (int64_t)(s0 + u) + kq;
       const bool ok = e < r1;
 #pragma unroll
@@ -1535,7 +1536,7 @@ __global__ __launch_bounds__(256) void k_wgrad_partial(const float* __restrict__
       x[u] = ok ? *(const f32x4v*)(xp + e * K) : zero;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int h = 0; h < MB; ++h)
 #pragma unroll
