@@ -205,7 +205,7 @@ def main():
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t1) / args.steps, err
 
-    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = None
+    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = None
     secondary_error = None
     kall = {}
     if rank == 0:
@@ -218,6 +218,35 @@ def main():
                 pair_ms, pair_err = timed(cst_mode="pair")                   # species-pair table
                 bf_ms, bf_err = timed(precision="bf16x3")                    # BASELINE config 3
                 bp_ms, bp_err = timed(precision="bf16x3", cst_mode="pair")
+            if not with_forces and args.workload == "cfg2":
+                # rows f3 of SURVEY.md 8: energy + autograd forces (reverse sweep) and one full training step, same batch
+                fm = build_model(dict(model_kw, regress_forces=True, direct_forces=False), 1234, dev)
+                with torch.no_grad():
+                    fm(batch)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(max(args.steps // 2, 2)):
+                        fm(batch)
+                    torch.cuda.synchronize()
+                    forces_ms = 1e3 * (time.perf_counter() - t1) / max(args.steps // 2, 2)
+                del fm
+                tm = build_model(model_kw, 1234, dev).train()
+                opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
+                target = torch.zeros(gen_kw["n_cells"], 1, device=dev)
+
+                def train_step():
+                    opt.zero_grad(set_to_none=True)
+                    torch.nn.functional.l1_loss(tm(batch), target).backward()
+                    opt.step()
+
+                train_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(max(args.steps // 4, 2)):
+                    train_step()
+                torch.cuda.synchronize()
+                train_ms = 1e3 * (time.perf_counter() - t1) / max(args.steps // 4, 2)
+                del tm, opt
         except Exception as e:  # noqa: BLE001
             secondary_error = f"{type(e).__name__}: {e}"
 
@@ -285,6 +314,15 @@ def main():
             "with_pair_table": None if bp_ms is None else {
                 "ms_per_step_rank0": round(bp_ms, 3), "edges_per_s_rank0": E / (bp_ms * 1e-3),
                 "max_rel_diff_vs_fp32_output": bp_err}}
+        if forces_ms is not None:
+            line["autograd_forces_mode"] = {
+                "note": "NOT the headline: regress_forces=True, direct_forces=False — energy and F = -dE/dpos by the HIP reverse "
+                        "sweep (species-pair forward)", "ms_per_step_rank0": round(forces_ms, 3),
+                "edges_per_s_rank0": E / (forces_ms * 1e-3)}
+        if train_ms is not None:
+            line["training_step_mode"] = {
+                "note": "NOT the headline: train mode, forward + HIP backward (all parameter gradients) + Adam step",
+                "ms_per_step_rank0": round(train_ms, 3), "edges_per_s_rank0": E / (train_ms * 1e-3)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
