@@ -913,6 +913,30 @@ def test_md_energy_conservation_with_captured_forces(dev):
     assert drift < 1e-5 and drift < 2e-2 * pe_change, (drift, pe_change)
 
 
+def test_error_behaviour(dev):
+    """Errors surface as exceptions with the library's message, never as silent fallbacks: unsupported fused widths,
+    wrong dtypes / devices, the reference's own ValueError for a missing valence mask (lcaonet.py:160-161)."""
+    from lcaonet_amd import _lib, ops
+    from lcaonet_amd.model.lcaonet import LCAOInteraction
+    x = torch.zeros(32, 48, device=dev)
+    w = torch.zeros(48, 48, device=dev)
+    with pytest.raises(_lib.LcaoHipError, match="not supported"):
+        ops.edge_lcao_weight(x, x, w, w)                       # fused two-body kernel exists for V in {32, 64, 128}
+    with pytest.raises(TypeError):
+        ops.dense(x.double(), w)
+    with pytest.raises(_lib.LcaoHipError, match="no CPU fallback"):
+        ops.dense(x.cpu(), w.cpu())
+    with pytest.raises(ValueError):
+        ops.dense(x, torch.zeros(48, 32, device=dev))
+    layer = LCAOInteraction(16, 16, 16, add_valence=True).to(dev)
+    e = torch.zeros(4, dtype=torch.long, device=dev)
+    with pytest.raises(ValueError, match="valence_mask"):
+        layer(torch.zeros(3, 16, device=dev), torch.zeros(4, 2, 16, device=dev), None, torch.zeros(4, 2, device=dev),
+              torch.zeros(0, 2, device=dev), e, e, e[:0], e[:0], e[:0])
+    for code in (0, -1, -2, -99, 1):
+        assert _lib.load().lcao_error_string(code).decode()    # every code has a message (> 0: hipGetErrorString)
+
+
 def test_segment_sum_kernels(dev):
     """lcao_segment_sum (+ optional row-wise multiplier) and lcao_segment_sum_gather against index_add in fp64: the 16-byte
     kernels (widths 32 / 64 / 128 / 256), the scalar kernels (3, 20, 1024), empty and very long segments; bitwise
