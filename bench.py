@@ -280,6 +280,26 @@ def main():
                         "traffic": pmc_traffic("lcao_triplet_gemm") if args.workload == "cfg2" else None,
                         "avg_launch_ms": round(per_launch_ms, 4), "launches": calls,
                         "algorithmic_bytes_per_launch": byts}
+        # every edge-level kernel against its own bound (per-launch averages of the separate fully bracketed pass, which
+        # run ~3 % longer than in the timed region because of the event pairs): algorithmic work as in DESIGN.md section 4
+        per_kernel = {}
+        work = {  # entry point: (bound, algorithmic flop or bytes per edge)
+            "lcao_coeff_mlp_contract": ("mfma", 2.0 * D * (C * V + V * V)),
+            "lcao_edge_lcao_weight": ("mfma", 4.0 * V * V),
+            "lcao_edge_node_message": ("mfma", 2.0 * V * V),
+            "lcao_triplet_gemm": ("hbm", 4 * n_l * V + 52 + 4 * V),
+            "lcao_embed_coeffs": ("hbm", 4 * D * C),
+        }
+        for kname, (bound, per_edge) in work.items():
+            if kname in kall and kall[kname][0] > 0:
+                calls, ms = kall[kname]
+                if kname == "lcao_embed_coeffs":
+                    calls, ms = args.steps, ms          # the pair-table launches of other modes are tiny; one real launch per step
+                rate = per_edge * E / (ms / calls * 1e-3)
+                peak = PEAK_F32_MFMA_TFLOPS * 1e12 if bound == "mfma" else PEAK_HBM_GBS * 1e9
+                per_kernel[kname] = {"bound": bound, "avg_launch_ms": round(ms / calls, 4),
+                                     "achieved": round(rate / (1e12 if bound == "mfma" else 1e9), 1),
+                                     "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(rate / peak, 4)}
         shape = (f"{gen_kw['n_mol']} random molecules of 3..29 atoms" if gen_kw.get("molecules") else
                  f"{gen_kw['n_cells']} jittered {gen_kw['n_side']}^3 simple-cubic crystals")
         line = {
@@ -296,6 +316,7 @@ def main():
             "roofline": roof, "roofline_hbm": roof_hbm,
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kall.items(), key=lambda kv: -kv[1][1])},
             "kernel_ms_per_step_note": "separate pass after the timed region with every C-ABI call bracketed by HIP events",
+            "kernel_rooflines": per_kernel,
         }
         if pair_ms is not None:
             line["pair_table_mode"] = {
