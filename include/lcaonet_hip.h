@@ -96,6 +96,13 @@ int lcao_nl_search(const float* wpos, const int32_t* wrap, const int64_t* batch,
 int lcao_dense(const float* X, int64_t ldx, const float* W, const float* bias, const float* residual, int64_t ldr,
                float* Y, int64_t ldy, int64_t M, int K, int N, int act, void* stream);
 
+/* Node-level tables of one LCAOInteraction in one launch (lcaonet.py:167 node_weight, :187 sigmoid(xk), first f_node
+ * layer of :209 split as Dense(cat[x_s,x_t]) = x_s Wa^T + x_t Wb^T):  [gate | Ps | Pt] = x . w_cat^T + b_cat with
+ * w_cat (3V, H) = [Wk; Wa Ws; Wb Ws] folded by the caller, sigmoid on the first V columns; three (n_rows, V) outputs
+ * (each nullable).  H % 16 == 0, V % 32 == 0. */
+int lcao_node_tables(const float* x, const float* w_cat, const float* b_cat, int64_t n_rows, int H, int V, float* gate,
+                     float* Ps, float* Pt, void* stream);
+
 /* a8  torch_scatter.scatter(reduce="sum") over CONTIGUOUS segments (index sorted): out[i] = sum_{r in [ptr[i],ptr[i+1])} a[r]*b[r]
  * (b nullable => plain segment sum).  Call sites lcaonet.py:189,208-213,293,307.  Deterministic (no atomics). */
 int lcao_segment_sum(const float* a, const float* b, const int32_t* ptr, int64_t n_seg, int width, float* out,

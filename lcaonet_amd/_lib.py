@@ -27,6 +27,7 @@ SIGNATURES = {
     "lcao_nl_bin_sort": [P, P, P, L, L, P, P, P, P, P, c_size_t, P],
     "lcao_nl_search": [P, P, P, P, P, P, L, F, I, P, P, P, P, P, P, P],
     "lcao_dense": [P, L, P, P, P, L, P, L, L, I, I, I, P],
+    "lcao_node_tables": [P, P, P, L, I, I, P, P, P, P],
     "lcao_segment_sum": [P, P, P, L, I, P, P],
     "lcao_segment_sum_gather": [P, P, P, L, I, P, P],
     "lcao_gather_rows": [P, P, L, I, P, P],

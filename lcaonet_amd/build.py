@@ -9,7 +9,7 @@ import time
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(CSRC, "liblcaonet_hip.so")
-SOURCES = ["lcao_generic.hip", "lcao_mfma.hip", "lcao_csr.hip", "lcao_neighbors.hip", "lcao_backward.hip"]
+SOURCES = ["lcao_generic.hip", "lcao_mfma.hip", "lcao_node.hip", "lcao_csr.hip", "lcao_neighbors.hip", "lcao_backward.hip"]
 
 
 def _newer(a: str, b: str) -> bool:
@@ -20,7 +20,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | No
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(REPO, "include"), "-I", CSRC,
              "-Wall", "-Wno-unused-function"] + (extra_flags or [])
-    headers = [os.path.join(CSRC, "lcao_common.h"), os.path.join(REPO, "include", "lcaonet_hip.h")]
+    headers = [os.path.join(CSRC, "lcao_common.h"), os.path.join(CSRC, "lcao_mfma.h"), os.path.join(REPO, "include", "lcaonet_hip.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

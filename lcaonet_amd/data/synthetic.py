@@ -172,6 +172,103 @@ def jittered_cubic_crystal(n_side: int, a: float = 3.2, sigma: float = 0.05, cut
     return make_graph(z, pos, lattice, cutoff_graph, None, None, max_neighbors)
 
 
+def _crystal_atoms(n_side: int, a: float, sigma: float, max_z: int, seed: int, dtype=torch.float32):
+    """pos (n, 3) and z (n) of jittered_cubic_crystal's atoms (x-major grid order), on the CPU: the same generator
+    stream, so a slab cut from here is a piece of exactly that crystal."""
+    g = torch.Generator().manual_seed(seed)
+    n = n_side**3
+    r = torch.arange(n_side, dtype=torch.float64)
+    grid = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1).reshape(n, 3) * a
+    pos = (grid + torch.randn(n, 3, generator=g, dtype=torch.float64) * (sigma * a)).to(dtype)
+    z = torch.randint(1, max_z + 1, (n,), generator=g)
+    return pos, z
+
+
+def slab_layers(n_side: int, world: int) -> list[tuple[int, int]]:
+    """x-layers [x0, x1) owned by each rank: whole layers, sizes differing by at most one."""
+    base, rem = divmod(n_side, world)
+    out, s = [], 0
+    for r in range(world):
+        e = s + base + (1 if r < rem else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def jittered_cubic_crystal_slab(n_side: int, rank: int, world: int, a: float = 3.2, sigma: float = 0.05,
+                                cutoff_graph: float = 5.94, max_neighbors: int | None = 32, max_z: int = 36,
+                                seed: int = 1234, device="cuda", dtype=torch.float32):
+    """Rank `rank`'s piece of jittered_cubic_crystal(n_side, ...) cut into `world` slabs of whole x-layers, built
+    WITHOUT the global graph: only the atom coordinates are global (one seeded stream, 24 B per atom); the neighbour
+    search runs on the rank's window = its layers plus a halo of ceil((2 cutoff + 8 sigma a) / a) layers on each side
+    (the sources k of in-edges k->s keep their `max_neighbors` nearest, which needs k's whole neighbourhood).
+
+    Returns (graph, node_gid, n_own, owner_of): the local graph with owned atoms first then ghosts, every owned
+    out-edge and every in-edge of an owned atom, original (wrapped) coordinates and lattice-unit shifts exactly as in the
+    unsharded crystal; global atom ids; `owner_of(gids) -> ranks`.  Feed to shard.plan_from_local."""
+    from .graph import Data
+
+    pos_all, z_all = _crystal_atoms(n_side, a, sigma, max_z, seed, dtype)
+    layers = slab_layers(n_side, world)
+    x0, x1 = layers[rank]
+    halo = int(math.ceil((2.0 * cutoff_graph + 8.0 * sigma * a) / a))
+    L = n_side * a
+    per_layer = n_side * n_side
+    bounds = torch.tensor([e for _, e in layers])
+
+    def owner_of(gid):
+        return torch.searchsorted(bounds.to(gid.device), torch.div(gid, per_layer, rounding_mode="floor"), right=True)
+
+    whole = (x1 - x0) + 2 * halo >= n_side      # the window would wrap onto itself: search the whole periodic crystal
+    if whole:
+        lay = torch.arange(n_side)
+        wrap = torch.zeros(n_side, dtype=torch.long)
+    else:
+        lay_u = torch.arange(x0 - halo, x1 + halo)                  # unwrapped layer indices
+        wrap = torch.div(lay_u, n_side, rounding_mode="floor")
+        lay = lay_u - wrap * n_side
+    gid = (lay.unsqueeze(1) * per_layer + torch.arange(per_layer).unsqueeze(0)).reshape(-1)      # window atoms
+    wrap_a = wrap.repeat_interleave(per_layer)
+    wpos = pos_all[gid].clone()
+    zz = z_all[gid]
+    if whole:
+        lat_search = torch.eye(3, dtype=dtype) * L
+    else:
+        # unwrapped x, shifted into a cell whose x edge leaves > cutoff of vacuum: periodic images along x never touch
+        wpos[:, 0] += (wrap_a.to(dtype) * L - float((x0 - halo) * a) + cutoff_graph + 1.0)
+        ext = (x1 - x0 + 2 * halo) * a + 2.0 * (cutoff_graph + 1.0)
+        lat_search = torch.diag(torch.tensor([ext, L, L], dtype=dtype))
+    if torch.device(device).type == "cuda":
+        from .neighbors import neighbor_list
+
+        ei, shift, _ = neighbor_list(wpos.to(device), lat_search.unsqueeze(0).to(device), cutoff_graph, None, None,
+                                     max_neighbors)
+    else:   # brute force (toy sizes: CPU tests of the planner)
+        c, nb, shift = _neighbor_list_cells(wpos.unsqueeze(0), torch.diagonal(lat_search).unsqueeze(0), cutoff_graph,
+                                            max_neighbors, True)
+        ei = torch.stack([c, nb])
+    gid, wrap_a = gid.to(device), wrap_a.to(device)
+    own_w = owner_of(gid) == rank          # the window never wraps onto itself, so every owned atom appears once
+    keep = own_w[ei[0]] | own_w[ei[1]]
+    es, et, sh = ei[0][keep], ei[1][keep], shift[keep].clone()
+    if not whole:
+        sh[:, 0] = (wrap_a[et] - wrap_a[es]).to(sh.dtype)         # x shift in units of the real lattice
+    used = torch.zeros(gid.numel(), dtype=torch.bool, device=device)
+    used[es] = True
+    used[et] = True
+    used &= ~own_w
+    own_i = own_w.nonzero(as_tuple=True)[0]
+    gh_i = used.nonzero(as_tuple=True)[0]
+    nodes = torch.cat([own_i, gh_i])
+    local_of = torch.full((gid.numel(),), -1, dtype=torch.long, device=device)
+    local_of[nodes] = torch.arange(nodes.numel(), device=device)
+    g = Data(z=zz.to(device)[nodes].contiguous(), pos=pos_all.to(device)[gid[nodes]].contiguous(),
+             edge_index=torch.stack([local_of[es], local_of[et]]).contiguous(), edge_shift=sh.contiguous(),
+             lattice=(torch.eye(3, dtype=dtype) * L).unsqueeze(0).to(device),
+             batch=torch.zeros(nodes.numel(), dtype=torch.long, device=device))
+    return g, gid[nodes].contiguous(), int(own_i.numel()), owner_of
+
+
 def random_molecule_batch(n_mol: int, min_atoms: int = 3, max_atoms: int = 29, species=(1, 6, 7, 8, 9),
                           cutoff_graph: float = 5.94, density: float = 0.08, seed: int = 1234, device="cuda",
                           max_neighbors: int | None = None, dtype=torch.float32) -> Batch:

@@ -220,28 +220,83 @@ class LCAOInteraction(nn.Module):
         acts_silu = all(type(m) is nn.SiLU for m in (self.f_coeffs[1], self.f_coeffs[3], self.f_node[1], self.f_node[3]))
         return acts_silu and (C, V) in ops.FUSED_COEFF_SHAPES
 
+    # node-level tables of the layer: gate = sigmoid(xk), Ps / Pt = the two halves of f_node.0 applied to xs
+    def _folded_node_weights(self) -> tuple[Tensor, Tensor]:
+        """[Wk; Wa Ws; Wb Ws] (3V, H) and [bk; Wa bs + b1; Wb bs] (3V) for lcao_node_tables — node_weight and the first
+        f_node layer are both linear, so Ps = (x Ws^T + bs) Wa^T + b1 = x (Wa Ws)^T + (Wa bs + b1).  Weights only;
+        cached until a parameter changes (data pointer or version counter)."""
+        ps = (self.node_weight.weight, self.node_weight.bias, self.f_node[0].weight, self.f_node[0].bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cached = self.__dict__.get("_fold")
+        if cached is not None and cached[0] == key:
+            return cached[1], cached[2]
+        V = self.emb_size_conv
+        wn, bn_, w1, b1 = (p.detach() for p in ps)
+        Ws, Wk, bs, bk = wn[:V], wn[V:], bn_[:V], bn_[V:]
+        Wa, Wb = w1[:, :V].contiguous(), w1[:, V:].contiguous()
+        WsT = Ws.t().contiguous()
+        w_cat = torch.cat([Wk, ops.dense(WsT, Wa).t(), ops.dense(WsT, Wb).t()], dim=0).contiguous()
+        b_cat = torch.cat([bk, ops.dense(bs.unsqueeze(0), Wa, b1)[0], ops.dense(bs.unsqueeze(0), Wb)[0]]).contiguous()
+        self.__dict__["_fold"] = (key, w_cat, b_cat)
+        return w_cat, b_cat
+
+    def _node_level(self, x: Tensor, gate: Tensor, Ps: Tensor | None, Pt: Tensor) -> None:
+        """Fill gate / Ps / Pt (row blocks matching x's rows; Ps may be None) — one launch when the widths allow."""
+        V, H = self.emb_size_conv, x.shape[1]
+        if V % 32 == 0 and H % 16 == 0 and H <= 512:
+            w_cat, b_cat = self._folded_node_weights()
+            ops.node_tables(x, w_cat, b_cat, V, out=(gate, Ps, Pt))
+            return
+        wn, bn_ = self.node_weight.weight.detach(), self.node_weight.bias.detach()
+        w1 = self.f_node[0].weight.detach()
+        xs = ops.dense(x, wn[:V], bn_[:V])
+        ops.dense(x, wn[V:], bn_[V:], ops.ACT_SIGMOID, out=gate)
+        if Ps is not None:
+            ops.dense(xs, w1[:, :V].contiguous(), self.f_node[0].bias.detach(), out=Ps)
+        ops.dense(xs, w1[:, V:].contiguous(), out=Pt)
+
     @torch.no_grad()
     def forward_fused(self, x: Tensor, cst: Tensor, valence_ed: Tensor | None, rb: Tensor, uvec: Tensor,
                       ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
                       trace: dict | None = None, exact_norm: bool = False, n_own: int | None = None,
-                      e_own: int | None = None, pair: tuple | None = None, precision: str = "fp32") -> Tensor:
+                      e_own: int | None = None, pair: tuple | None = None, precision: str = "fp32",
+                      ghost_fn=None) -> Tensor:
         """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1.
 
         n_own / e_own (sharded graphs, lcaonet_amd/shard.py): only the first n_own nodes are centres to update and
         only the first e_own edges of p-space carry messages; the remaining (ghost) nodes and their out-edges feed the
-        three-body and two-body terms.  Returns the new state of the n_own centre nodes."""
+        three-body and two-body terms.  Returns the new state of the n_own centre nodes.
+
+        ghost_fn (sharded graphs): x then holds the n_own OWNED rows only and ghost_fn() returns the ghost rows — it is
+        called as late as possible: the node tables of the owned rows and the coefficient kernel over the owned-centre
+        edges [0, e_own) are enqueued first, so a halo exchange still in flight overlaps with ~96 % of the layer's
+        matrix work."""
         V = self.emb_size_conv
-        N = x.size(0)
+        N = ctx.n_nodes
         n_own = N if n_own is None else n_own
         e_own = ctx.n_edges if e_own is None else e_own
+        E, dev = ctx.n_edges, x.device
         if fused is None:
             fused = self._fusable(V if pair is not None else cst.shape[-1])
-        wn, bn_ = self.node_weight.weight.detach(), self.node_weight.bias.detach()
-        xs = ops.dense(x, wn[:V], bn_[:V])
-        gate = ops.dense(x, wn[V:], bn_[V:], ops.ACT_SIGMOID)           # sigmoid(xk), gathered per triplet
-        w1 = self.f_node[0].weight.detach()
-        Ps = ops.dense(xs[:n_own], w1[:, :V].contiguous(), self.f_node[0].bias.detach())
-        Pt = ops.dense(xs, w1[:, V:].contiguous())
+        split = (ghost_fn is not None and fused and pair is None and precision == "fp32" and not exact_norm
+                 and not self.add_valence and N > n_own)
+        if ghost_fn is not None and not split:
+            xg = ghost_fn()
+            x = torch.cat([x, xg], dim=0) if xg.shape[0] else x
+        rows = x.shape[0]            # n_own when the ghost rows are still in flight, else every local row
+        new = lambda n: torch.empty(n, V, device=dev, dtype=torch.float32)
+        gate, Pt, Ps = new(N), new(N), new(rows)
+        self._node_level(x, gate[:rows], Ps, Pt[:rows])
+        k2_out = None
+        if split:
+            k2_out = ops.coeff_mlp_buffers(E, V, n_l, dev, True, False)
+            k2 = lambda rng: ops.coeff_mlp_contract(
+                cst, rb, ctx.order, l_of_d, None, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(),
+                n_l, False, gate=gate, src_p=ctx.src_p, p_range=rng, out=k2_out)
+            k2((0, e_own))                                           # owned centres: gate rows [0, n_own) only
+            xg = ghost_fn()
+            self._node_level(xg, gate[rows:], None, Pt[rows:])
+            Ag, gram, B, Bv = k2((e_own, E))                         # ghost-centred in-edges of owned nodes
         out_ptr, in_ptr = ctx.out_ptr[: n_own + 1], ctx.in_ptr[: n_own + 1]
         src_own, dst_own = ctx.src_p[:e_own], ctx.dst_p[:e_own]
         # coefficient MLP + radial contraction (all local edges), then the three-body term (owned centres)
@@ -271,10 +326,11 @@ class LCAOInteraction(nn.Module):
             else:
                 tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
         elif fused:
-            Ag, gram, B, Bv = ops.coeff_mlp_contract(
-                cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
-                self.f_coeffs[2].weight.detach(), n_l, self.add_valence,
-                gate=None if exact_norm else gate, src_p=ctx.src_p)
+            if not split:
+                Ag, gram, B, Bv = ops.coeff_mlp_contract(
+                    cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
+                    self.f_coeffs[2].weight.detach(), n_l, self.add_valence,
+                    gate=None if exact_norm else gate, src_p=ctx.src_p)
             if exact_norm:   # per-triplet V-long norm (validation of the Gram-matrix form)
                 tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
             else:
@@ -429,15 +485,17 @@ class LCAONet(BaseMPNN):
                                                         graph[GraphKeys.Edge_idx_ks_3b])
         return graph
 
-    # --- one graph sharded over several GPUs (lcaonet_amd/shard.py) ---------------------------------------------
+    # --- one graph sharded over several GPUs (lcaonet_amd/shard.py, model/sharded.py) ------------------------------
     @torch.no_grad()
     def forward_sharded(self, plan, exchange_fn=None, reduce_fn=None, group=None, fused: bool | None = None,
                         reverse_fn=None):
-        """This rank's part of forward() on a graph partitioned by centre node.  `plan` = shard.make_plans(...)[rank].
-        Collectives: L-1 all-gathers of boundary node rows (exchange_fn, default shard.exchange_ghosts over `group`)
-        and one all-reduce of the (B, out) per-graph partial sums (reduce_fn).  Returns the global (B, out) result
-        (identical on every rank) or ((B, out), forces of the owned nodes)."""
+        """This rank's part of forward() on a graph partitioned by centre node.  `plan` = shard.make_plans(...)[rank] or
+        shard.plan_from_local(...).  Collectives: L-1 all-to-alls of boundary node rows (asynchronous, overlapped with
+        the next layer's coefficient kernel; exchange_fn(x_own) -> ghost rows replaces them, synchronously) and one
+        all-reduce of the (B, out) per-graph partial sums (reduce_fn).  Returns the global (B, out) result (identical
+        on every rank) or ((B, out), forces of the owned nodes)."""
         from .. import shard
+        from .sharded import ShardedForward
 
         if self.training:
             raise NotImplementedError("forward_sharded: eval mode only (BatchNorm batch statistics would need a collective)")
@@ -446,50 +504,22 @@ class LCAONet(BaseMPNN):
             from .forces import run_sharded_forces
 
             return run_sharded_forces(self, plan, group, exchange_fn, reduce_fn, reverse_fn)
-        exchange_fn = exchange_fn or (lambda x_own: shard.exchange_ghosts(plan, x_own, group))
         reduce_fn = reduce_fn or (lambda part: shard.reduce_graph_outputs(part, group))
-        graph = plan.graph
-        z, pos = graph[GraphKeys.Z], graph[GraphKeys.Pos]
-        idx_s, idx_t = graph[GraphKeys.Edge_idx]
-        n_own, e_own = plan.n_own, plan.e_own
-        ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], z.size(0))
-        graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
-        dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
-        rb = self.rbf(dist)
-        x, cst = self.emb_layer.forward_species(z, ctx)   # static inputs only: ghosts need no exchange for x0
-        valence_ed = self.valence_mask.per_edge(z, idx_t) if self.add_valence else None
-
-        def layer_fn(i, x_local):
-            return self.int_layers[i].forward_fused(x_local, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l,
-                                                    fused, None, False, n_own, e_own)
-
-        x_own = shard.run_sharded_layers(plan, x, self.n_interaction, layer_fn, exchange_fn)
-        # output head on the owned nodes; per-graph reduction = local partial sums + one small all-reduce
-        batch_own = graph[GraphKeys.Batch_idx][:n_own]
-        prop = run_mlp(self.out_layer.out_lin, x_own)
-        part = scatter(prop, batch_own, dim=0, dim_size=plan.n_graphs, reduce="sum")
-        z_own = z[:n_own]
-        ones = torch.ones(n_own, 1, device=prop.device)
-        extra = [scatter(ones, batch_own, dim=0, dim_size=plan.n_graphs, reduce="sum")]
-        if self.pp_layer.atomref is not None:
-            extra.append(scatter(self.pp_layer.atomref[z_own].float().contiguous(), batch_own, dim=0,
-                                 dim_size=plan.n_graphs, reduce="sum"))
-        tot = reduce_fn(torch.cat([part] + extra, dim=1))
-        out, cnt = tot[:, : self.out_size], tot[:, self.out_size: self.out_size + 1]
-        ext = self.out_layer.is_extensive
-        if not ext:
-            out = out / cnt.clamp(min=1)
-        if self.pp_layer.atomref is not None:
-            aref = tot[:, self.out_size + 1:]
-            out = out + (aref if self.pp_layer.is_extensive else aref / cnt.clamp(min=1))
-        if self.pp_layer.mean is not None:
-            out = out + (self.pp_layer.mean.unsqueeze(0) * cnt if self.pp_layer.is_extensive else self.pp_layer.mean.unsqueeze(0))
-        if self.regress_forces:  # direct forces of the owned centres (their out-edges are all local)
-            own_e = idx_s < n_own
-            es, et = idx_s[own_e], idx_t[own_e]
-            xl = torch.cat([x_own, exchange_fn(x_own)], dim=0) if plan.n_ghost else x_own
-            f = run_mlp(self.out_layer.out_lin_force, torch.cat([xl[es], xl[et]], dim=-1)) * uvec[own_e]
-            return out, scatter(f, es, dim=0, dim_size=n_own)
+        sf = ShardedForward(self, plan, fused)
+        pending = None
+        for i in range(self.n_interaction):
+            if i == 0:
+                x_own = sf.layer(0, None)
+            elif exchange_fn is not None:
+                x_own = sf.layer(i, lambda x_prev=x_own: exchange_fn(x_prev))
+            else:
+                x_own = sf.layer(i, pending.wait)
+            if i + 1 < self.n_interaction and exchange_fn is None:
+                pending = shard.start_exchange(plan, x_own, group)
+        out = sf.finish(reduce_fn(sf.head_partial()))
+        if self.regress_forces:   # direct forces of the owned centres (their out-edges are all local)
+            ghosts = exchange_fn(x_own) if exchange_fn is not None else shard.exchange_ghosts(plan, x_own, group)
+            return out, sf.direct_forces(ghosts)
         return out
 
     # --- forward ------------------------------------------------------------------------------------------

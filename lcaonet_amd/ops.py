@@ -159,8 +159,9 @@ def triplet_angles(uvec: Tensor, e_st: Tensor, e_ks: Tensor) -> Tensor:
 
 
 def dense(x: Tensor, weight: Tensor, bias: Tensor | None = None, act: int = ACT_NONE,
-          residual: Tensor | None = None) -> Tensor:
-    """act(x @ weight.T + bias) + residual on the last dim of x (any leading dims)."""
+          residual: Tensor | None = None, out: Tensor | None = None) -> Tensor:
+    """act(x @ weight.T + bias) + residual on the last dim of x (any leading dims).  out: (M, N) contiguous rows to
+    write into (e.g. a row range of a larger table)."""
     x = _f32(x, "x")
     weight = _f32(weight, "weight")
     N, K = weight.shape
@@ -170,12 +171,35 @@ def dense(x: Tensor, weight: Tensor, bias: Tensor | None = None, act: int = ACT_
     x2 = x.reshape(-1, K)
     M = x2.shape[0]
     bias = _f32(bias, "bias") if bias is not None else None
-    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    if out is not None:
+        if out.shape != (M, N) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("dense: out must be a contiguous float32 (M, N) block")
+        y = out
+    else:
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     r2 = None
     if residual is not None:
         r2 = _f32(residual, "residual").reshape(M, N)
     _call("lcao_dense", _p(x2), K, _p(weight), _p(bias), _p(r2), N, _p(y), N, M, K, N, act, _stream())
     return y.reshape(*lead, N)
+
+
+def node_tables(x: Tensor, w_cat: Tensor, b_cat: Tensor, V: int, out=None, want_ps: bool = True):
+    """(gate, Ps, Pt), each (M, V), from x (M, H) in one launch: [gate | Ps | Pt] = x w_cat^T + b_cat with sigmoid on the
+    gate columns (csrc/lcao_node.hip).  out: three preallocated (M, V) blocks (row ranges of larger tables)."""
+    x, w_cat, b_cat = _f32(x, "x"), _f32(w_cat, "w_cat"), _f32(b_cat, "b_cat")
+    M, H = x.shape
+    if w_cat.shape != (3 * V, H) or b_cat.numel() != 3 * V:
+        raise ValueError("node_tables: w_cat must be (3V, H) and b_cat (3V)")
+    if out is None:
+        new = lambda: torch.empty(M, V, device=x.device, dtype=torch.float32)
+        out = (new(), new() if want_ps else None, new())
+    gate, Ps, Pt = out
+    for t in out:
+        if t is not None and (t.shape != (M, V) or not t.is_contiguous()):
+            raise ValueError("node_tables: outputs must be contiguous (M, V) blocks")
+    _call("lcao_node_tables", _p(x), _p(w_cat), _p(b_cat), M, H, V, _p(gate), _p(Ps), _p(Pt), _stream())
+    return gate, Ps, Pt
 
 
 def segment_sum(a: Tensor, ptr: Tensor, b: Tensor | None = None) -> Tensor:
@@ -258,26 +282,41 @@ def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, sr
     return (Ag if gated else A), gram, B, None
 
 
-def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence, gate=None, src_p=None):
+def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence, gate=None, src_p=None, p_range=None,
+                       out=None):
     """Fused f_coeffs + radial contraction.  With `gate` (N,V) and `src_p`: returns (Ag, gram, B, Bv) for
-    triplet_gemm; without: (A, None, B, Bv) for the exact-norm triplet_sum."""
+    triplet_gemm; without: (A, None, B, Bv) for the exact-norm triplet_sum.
+    p_range = (p0, p1): only the edges [p0, p1) of p-space, written into rows [p0, p1) of `out` = the tuple a full call
+    returned or `coeff_mlp_buffers(...)` allocated (sharded graphs: the owned-centre edges run while the halo exchange
+    is in flight, the ghost-centred ones after it)."""
     cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
     E, D = rb.shape
     V, C = W1.shape
     dev = rb.device
     valence_ed = _f32(valence_ed) if valence else None
-    B = torch.empty(E, V, device=dev, dtype=torch.float32)
-    Bv = torch.empty(E, V, device=dev, dtype=torch.float32) if valence else None
     gated = gate is not None
-    A = torch.empty(E, n_l, V, device=dev, dtype=torch.float32) if (valence or not gated) else None
-    Ag = torch.empty(E, n_l, V, device=dev, dtype=torch.float32) if gated else None
-    gram = torch.empty(E, 10, device=dev, dtype=torch.float32) if gated else None
+    if out is None:
+        out = coeff_mlp_buffers(E, V, n_l, dev, gated, valence)
+    A, Ag, gram, B, Bv = out
     if gated:
         gate = _f32(gate, "gate")
-    ws = torch.empty(2, device=dev, dtype=torch.int32)  # tile-queue counters (the library zeroes them on the stream)
-    _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(order), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2), _p(gate),
-          _p(src_p), E, D, C, V, n_l, int(valence), _p(A), _p(B), _p(Bv), _p(Ag), _p(gram), _p(ws), 8, _stream())
+    p0, p1 = (0, E) if p_range is None else p_range
+    if p1 > p0:
+        sl = lambda t: None if t is None else t[p0:p1]
+        if order is None and p0 != 0:
+            raise ValueError("coeff_mlp_contract: a p-range needs the order array")
+        ws = torch.empty(2, device=dev, dtype=torch.int32)  # tile-queue counters (the library zeroes them on the stream)
+        _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(sl(order)), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2),
+              _p(gate), _p(sl(src_p)), p1 - p0, D, C, V, n_l, int(valence), _p(sl(A)), _p(sl(B)), _p(sl(Bv)), _p(sl(Ag)),
+              _p(sl(gram)), _p(ws), 8, _stream())
     return (Ag if gated else A), gram, B, Bv
+
+
+def coeff_mlp_buffers(E, V, n_l, dev, gated: bool, valence: bool):
+    """(A, Ag, gram, B, Bv) output buffers of coeff_mlp_contract (None where the mode does not produce one)."""
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    return (new(E, n_l, V) if (valence or not gated) else None, new(E, n_l, V) if gated else None,
+            new(E, 10) if gated else None, new(E, V), new(E, V) if valence else None)
 
 
 def pair_contract(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, n_l, zdim, visit=None):

@@ -4,22 +4,32 @@ The reference has no distributed code; this is the MI355X design for graphs that
 (BASELINE config 4: one 2 M-atom crystal).  Batches of independent crystals (config 2) shard by whole graphs and need
 none of this: zero halo, no data-path collective (bench.py).
 
-Partition.  Nodes are split into contiguous ranges (callers order nodes spatially / by graph); rank r OWNS the nodes of
-its range and every edge whose centre (`edge_index[0]`, the aggregation index, lcaonet.py:207-213) it owns, so all
-messages reduce locally — there is no cross-GPU reduction of node features.  To compute its owned nodes a rank also
-needs, per layer, the state x of its GHOST nodes: neighbours t of owned centres (two-body term, lcaonet.py:209) and the
-sources k of in-edges k->s of owned centres (three-body term, lcaonet.py:173-189).  Those in-edges are replicated on
-the rank (geometry, radial basis and coefficient vectors are functions of the static inputs z, pos), so the ONLY
-per-layer traffic is one all-gather of boundary node rows (n_boundary x H fp32), L-1 times per forward, plus one
-all-reduce of the (B, out) per-graph partial sums.  xGMI is point to point (7 links/GPU): the all-gather of packed
-boundary rows uses every link at once; nothing the size of x is ever ring-reduced.
+Partition.  Rank r OWNS a set of nodes (a contiguous range / a spatial slab) and every edge whose centre
+(`edge_index[0]`, the aggregation index, lcaonet.py:207-213) it owns, so all messages reduce locally — there is no
+cross-GPU reduction of node features.  To compute its owned nodes a rank also needs, per layer, the state x of its GHOST
+nodes: neighbours t of owned centres (two-body term, lcaonet.py:209) and the sources k of in-edges k->s of owned centres
+(three-body term, lcaonet.py:173-189).  Those in-edges are replicated on the rank (geometry, radial basis and
+coefficient vectors are functions of the static inputs z, pos), so the ONLY per-layer traffic is the boundary node rows.
 
-Autograd forces (model/forces.py::sharded_force_steps) add the same exchange run backwards: dE/dx of ghost nodes per
-layer and dE/dpos of ghost atoms return to their owners through ONE reduce-scatter of the slot buffer (reverse_exchange).
+Exchange.  xGMI is point to point (7 links per GPU), so the halo exchange is ONE `all_to_all_single` with exact split
+sizes per interaction (L-1 per forward): a rank sends each peer precisely the rows that peer holds as ghosts (a slab
+talks to its <= 2 neighbours, 2 x 16.8 MB at config 4) and receives its own ghost rows already in local order —
+ghosts are numbered by (owner rank, global id), which is the order the owners pack them in, so the receive buffer IS the
+ghost block of x (no unpack pass).  Nothing is padded to a common slot size and nothing is replicated to ranks that do
+not need it.  The exchange is asynchronous (`start_exchange`): the coefficient kernel of the next layer over the
+owned-centre edges (96 % of the layer's matrix work) needs owned rows only and runs under it
+(LCAOInteraction.forward_fused(ghost_fn=...)).  One all-reduce of the (B, out) per-graph partial sums closes a forward.
+
+Autograd forces (model/forces.py::sharded_force_steps) add the same exchange run backwards (`reverse_exchange`): dE/dx
+of ghost nodes per layer and dE/dpos of ghost atoms return to their owners with the split sizes swapped, and the owner
+sums what it received per node in a fixed order (sorted segments: bitwise reproducible).
+
+Plans.  `make_plans(graph, world)` cuts a graph every rank holds (tests, small graphs).  `plan_from_local(...)` builds a
+rank's plan from ITS OWN slab only — the global graph never exists anywhere; the send lists are negotiated with two
+plan-time all-to-alls (bench.py --workload cfg4, data/synthetic.py::jittered_cubic_crystal_slab).
 
 Local numbering: owned nodes first [0, n_own), ghosts after; edges sorted by centre then have the owned out-edges as a
-prefix [0, e_own) of p-space, so the kernels simply run with smaller counts (triplet / message kernels over n_own,
-e_own; the coefficient kernel over all local edges because ghost->owned edges feed the three-body term).
+prefix [0, e_own) of p-space, so the kernels simply run with smaller counts.
 """
 from __future__ import annotations
 
@@ -41,11 +51,17 @@ class ShardPlan:
     e_own: int
     graph: Data                 # local graph (owned + ghost nodes; local node ids; `batch` = global graph ids)
     owned_global: Tensor        # (n_own) global node ids
-    ghost_global: Tensor        # (n_ghost) global node ids (ascending)
-    send_idx: Tensor            # (n_send) local ids (< n_own) of owned nodes some other rank holds as ghosts
-    max_send: int               # max n_send over ranks (all-gather slot size)
-    ghost_flat: Tensor          # (n_ghost) index into the gathered (world * max_send) rows
+    ghost_global: Tensor        # (n_ghost) global node ids, ordered by (owner rank, global id)
+    send_idx: Tensor            # (n_send) local ids (< n_own) of the rows sent, concatenated by destination rank
+    send_splits: list           # (world) rows sent to each rank (this rank's entry is 0)
+    recv_splits: list           # (world) ghost rows received from each rank; sum = n_ghost
     n_graphs: int
+    rev_perm: Tensor            # (n_send) stable argsort of send_idx: received reverse rows grouped by owned node
+    rev_ptr: Tensor             # (n_own + 1) int32 segment pointers of rev_perm
+
+    @property
+    def n_send(self) -> int:
+        return int(self.send_idx.numel())
 
 
 def _node_ranges(n_nodes: int, world: int) -> list[tuple[int, int]]:
@@ -58,9 +74,18 @@ def _node_ranges(n_nodes: int, world: int) -> list[tuple[int, int]]:
     return out
 
 
+def _reverse_index(send_idx: Tensor, n_own: int) -> tuple[Tensor, Tensor]:
+    perm = torch.argsort(send_idx, stable=True)
+    cnt = torch.bincount(send_idx, minlength=n_own) if send_idx.numel() else torch.zeros(n_own, dtype=torch.long,
+                                                                                         device=send_idx.device)
+    ptr = torch.zeros(n_own + 1, dtype=torch.int32, device=send_idx.device)
+    ptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    return perm, ptr
+
+
 def make_plans(graph, world: int, ranges: list[tuple[int, int]] | None = None) -> list[ShardPlan]:
-    """Build the plan of every rank from the global graph (host-side index work with torch ops; run once per graph).
-    Every rank can call this on the replicated global graph and keep plans[rank]."""
+    """Plans of every rank from a graph the caller holds whole (host-side index work with torch ops; run once per
+    graph).  Contiguous node ranges; callers order nodes spatially / by graph."""
     z = graph[GraphKeys.Z]
     N = z.numel()
     dev = z.device
@@ -82,18 +107,8 @@ def make_plans(graph, world: int, ranges: list[tuple[int, int]] | None = None) -
         touched[es] = True
         touched[et] = True
         touched[a:b] = False
-        ghosts = touched.nonzero(as_tuple=True)[0]     # ascending global ids
+        ghosts = touched.nonzero(as_tuple=True)[0]     # ascending global ids = ordered by (owner, id) for ranges
         per_rank.append((e_mask, ghosts))
-
-    # boundary (send) sets: owned nodes that are ghosts anywhere else, in ascending global id
-    is_boundary = torch.zeros(N, dtype=torch.bool, device=dev)
-    for _, ghosts in per_rank:
-        is_boundary[ghosts] = True
-    send_global = [(is_boundary[a:b].nonzero(as_tuple=True)[0] + a) for (a, b) in ranges]
-    max_send = max(int(s.numel()) for s in send_global) if world > 0 else 0
-    slot_of = torch.full((N,), -1, dtype=torch.long, device=dev)   # global id -> flat slot in the gathered buffer
-    for r, s in enumerate(send_global):
-        slot_of[s] = r * max_send + torch.arange(s.numel(), device=dev)
 
     plans = []
     for r, (a, b) in enumerate(ranges):
@@ -110,71 +125,148 @@ def make_plans(graph, world: int, ranges: list[tuple[int, int]] | None = None) -
             edge_shift=graph[GraphKeys.Edge_shift][e_mask].contiguous(), lattice=lattice,
             batch=(batch[nodes].contiguous() if batch is not None else torch.zeros(nodes.numel(), dtype=torch.long, device=dev)),
         )
+        # what this rank sends to q = q's ghosts that this rank owns, ascending (the order q numbers them in)
+        sends = [per_rank[q][1][(per_rank[q][1] >= a) & (per_rank[q][1] < b)] - a if q != r
+                 else torch.zeros(0, dtype=torch.long, device=dev) for q in range(world)]
+        send_idx = torch.cat(sends) if world > 0 else torch.zeros(0, dtype=torch.long, device=dev)
+        recv_splits = torch.bincount(owner[ghosts], minlength=world).tolist() if n_ghost else [0] * world
+        perm, ptr = _reverse_index(send_idx, n_own)
         plans.append(ShardPlan(
             rank=r, world=world, n_own=n_own, n_ghost=n_ghost, e_own=int((es < n_own).sum()), graph=g,
-            owned_global=torch.arange(a, b, device=dev), ghost_global=ghosts, send_idx=(send_global[r] - a), max_send=max_send,
-            ghost_flat=slot_of[ghosts], n_graphs=n_graphs))
+            owned_global=torch.arange(a, b, device=dev), ghost_global=ghosts, send_idx=send_idx,
+            send_splits=[int(s.numel()) for s in sends], recv_splits=[int(c) for c in recv_splits], n_graphs=n_graphs,
+            rev_perm=perm, rev_ptr=ptr))
     return plans
 
 
-def pack_boundary(plan: ShardPlan, x_own: Tensor) -> Tensor:
-    """(max_send, H) send buffer: this rank's boundary rows, zero padded to the common slot size."""
-    buf = x_own.new_zeros((plan.max_send, x_own.shape[1]))
-    if plan.send_idx.numel():
-        buf[: plan.send_idx.numel()] = x_own[plan.send_idx]
-    return buf
+def _a2a(out: Tensor, inp: Tensor, out_splits, in_splits, group=None, async_op: bool = False):
+    """all_to_all_single; over gloo (CPU rehearsal of the RCCL path) device tensors are staged through the host."""
+    import torch.distributed as dist
+
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+        return None
+    return dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=group, async_op=async_op)
 
 
-def unpack_ghosts(plan: ShardPlan, gathered: Tensor) -> Tensor:
-    """gathered (world, max_send, H) -> (n_ghost, H) rows of this rank's ghosts."""
-    return gathered.reshape(-1, gathered.shape[-1])[plan.ghost_flat]
+def plan_from_local(rank: int, world: int, graph: Data, node_gid: Tensor, n_own: int, owner_of, n_graphs: int = 1,
+                    group=None) -> ShardPlan:
+    """A rank's plan from its OWN slab: `graph` holds the owned nodes first ([0, n_own)) then the ghosts in any order,
+    with every owned out-edge and every in-edge of an owned node; `node_gid` (n_local) are global ids and
+    `owner_of(gids) -> ranks` names their owners.  Ghosts are renumbered by (owner, global id) and the send lists come
+    from two plan-time all-to-alls (counts, then the requested ids) — collective: every rank of `group` must call."""
+    dev = node_gid.device
+    n_loc = int(node_gid.numel())
+    ghost_gid = node_gid[n_own:]
+    ghost_owner = owner_of(ghost_gid).to(torch.long)
+    key = ghost_owner * (int(node_gid.max().item()) + 1 if n_loc else 1) + ghost_gid
+    o = torch.argsort(key)
+    new_of_old = torch.arange(n_loc, device=dev)
+    new_of_old[n_own + o] = n_own + torch.arange(o.numel(), device=dev)      # old local id -> new local id
+    old_of_new = torch.cat([torch.arange(n_own, device=dev), n_own + o])
+    ei = new_of_old[graph[GraphKeys.Edge_idx]]
+    g = Data(**{k: v for k, v in graph.to_dict().items()})
+    for k in (GraphKeys.Z, GraphKeys.Pos, GraphKeys.Batch_idx):
+        if g.get(k) is not None:
+            g[k] = g[k][old_of_new].contiguous()
+    g[GraphKeys.Edge_idx] = ei.contiguous()
+    ghost_gid, ghost_owner = ghost_gid[o], ghost_owner[o]
+    recv_cnt = torch.bincount(ghost_owner, minlength=world) if o.numel() else torch.zeros(world, dtype=torch.long, device=dev)
+    send_cnt = torch.empty_like(recv_cnt)
+    if world > 1:
+        _a2a(send_cnt, recv_cnt, None, None, group)
+    else:
+        send_cnt.copy_(recv_cnt)
+    recv_splits, send_splits = [int(c) for c in recv_cnt.tolist()], [int(c) for c in send_cnt.tolist()]
+    req = torch.empty(sum(send_splits), dtype=torch.long, device=dev)
+    if world > 1:
+        _a2a(req, ghost_gid.contiguous(), send_splits, recv_splits, group)     # ids the peers want from me
+    own_gid = node_gid[:n_own]
+    srt = torch.argsort(own_gid)
+    pos_in = torch.searchsorted(own_gid[srt], req)
+    if req.numel() and not bool((own_gid[srt][pos_in.clamp(max=max(n_own - 1, 0))] == req).all()):
+        raise ValueError("plan_from_local: a peer requested a node this rank does not own (owner_of disagrees)")
+    send_idx = srt[pos_in] if req.numel() else req
+    perm, ptr = _reverse_index(send_idx, n_own)
+    return ShardPlan(rank=rank, world=world, n_own=n_own, n_ghost=n_loc - n_own, e_own=int((ei[0] < n_own).sum()), graph=g,
+                     owned_global=own_gid, ghost_global=ghost_gid, send_idx=send_idx, send_splits=send_splits,
+                     recv_splits=recv_splits, n_graphs=n_graphs, rev_perm=perm, rev_ptr=ptr)
+
+
+# --- forward halo exchange ---------------------------------------------------------------------------------------
+class _Pending:
+    """An exchange in flight: `wait()` returns the (n_ghost, H) ghost rows (the current stream waits, not the host)."""
+
+    def __init__(self, recv: Tensor, work, keep):
+        self.recv, self.work, self.keep = recv, work, keep
+
+    def wait(self) -> Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.keep = None
+        return self.recv
+
+
+def start_exchange(plan: ShardPlan, x_own: Tensor, group=None, out: Tensor | None = None) -> _Pending:
+    """Launch ONE all-to-all of boundary rows (backend 'nccl' = RCCL over xGMI on ROCm; 'gloo' on CPU).  `out`: the
+    (n_ghost, H) block to receive into (e.g. the ghost rows of the next layer's x)."""
+    recv = out if out is not None else x_own.new_empty((plan.n_ghost, x_own.shape[1]))
+    if plan.world == 1 or (plan.n_ghost == 0 and plan.n_send == 0):
+        return _Pending(recv, None, None)
+    send = x_own[plan.send_idx]
+    work = _a2a(recv, send, plan.recv_splits, plan.send_splits, group, async_op=True)
+    return _Pending(recv, work, send)
 
 
 def exchange_ghosts(plan: ShardPlan, x_own: Tensor, group=None) -> Tensor:
-    """ONE collective: all-gather of packed boundary rows (backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' on CPU)."""
-    import torch.distributed as dist
-
-    send = pack_boundary(plan, x_own)
-    recv = send.new_empty((plan.world,) + tuple(send.shape))
-    if plan.max_send > 0:
-        dist.all_gather_into_tensor(recv.view(-1, send.shape[1]), send, group=group)
-    return unpack_ghosts(plan, recv)
+    return start_exchange(plan, x_own, group).wait()
 
 
-def scatter_ghost_rows(plan: ShardPlan, g_ghost: Tensor) -> Tensor:
-    """(n_ghost, W) rows held for ghost nodes -> the (world * max_send, W) slot buffer of the forward all-gather with
-    those rows at their owners' slots (zero elsewhere): the operand of the reverse collective."""
-    buf = g_ghost.new_zeros((plan.world * plan.max_send, g_ghost.shape[1]))
-    if plan.n_ghost:
-        buf[plan.ghost_flat] = g_ghost          # ghost_flat is injective: one slot per ghost
-    return buf
+def _sum_by_owned_node(plan: ShardPlan, rows: Tensor) -> Tensor:
+    """rows (n_send, W), row i belonging to owned node send_idx[i] -> (n_own, W) sums in a fixed order."""
+    if rows.is_cuda:
+        from . import ops
 
-
-def own_addend(plan: ShardPlan, slots: Tensor) -> Tensor:
-    """(max_send, W) reduced slot rows of THIS rank -> (n_own, W) addend for its owned nodes (zero for interior nodes)."""
-    out = slots.new_zeros((plan.n_own, slots.shape[1]))
-    n_send = plan.send_idx.numel()
-    if n_send:
-        out[plan.send_idx] = slots[:n_send]     # send_idx is injective
-    return out
+        return ops.segment_sum_gather(rows.contiguous(), plan.rev_perm.to(torch.int32), plan.rev_ptr)
+    return rows.new_zeros((plan.n_own, rows.shape[1])).index_add_(0, plan.send_idx, rows)
 
 
 def reverse_exchange(plan: ShardPlan, g_ghost: Tensor, group=None) -> Tensor:
-    """The forward halo all-gather run backwards: every rank contributes what it holds for its ghosts, every owner
-    receives the sum for its boundary nodes — ONE reduce-scatter of the slot buffer (RCCL); gloo has no
-    reduce-scatter, there an all-reduce of the slot buffer is sliced instead."""
-    import torch.distributed as dist
-
-    buf = scatter_ghost_rows(plan, g_ghost)
-    if plan.max_send == 0:
+    """The forward halo exchange run backwards: every rank returns what it holds for its ghosts, every owner receives
+    the rows for the nodes it sent (split sizes swapped) and sums them per node -> (n_own, W) addend (zero for interior
+    nodes)."""
+    if plan.world == 1 or (plan.n_ghost == 0 and plan.n_send == 0):
         return g_ghost.new_zeros((plan.n_own, g_ghost.shape[1]))
-    mine = buf.new_empty((plan.max_send, buf.shape[1]))
-    if dist.get_backend(group) == "gloo":
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        mine.copy_(buf[plan.rank * plan.max_send: (plan.rank + 1) * plan.max_send])
-    else:
-        dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=group)
-    return own_addend(plan, mine)
+    rows = g_ghost.new_empty((plan.n_send, g_ghost.shape[1]))
+    _a2a(rows, g_ghost, plan.send_splits, plan.recv_splits, group)
+    return _sum_by_owned_node(plan, rows)
+
+
+# --- the same data movement without a process group: every rank's plan in one process (lock-step tests) ----------
+def local_exchange(plans: list[ShardPlan], x_owns: list[Tensor]) -> list[Tensor]:
+    """What start_exchange(...).wait() returns on every rank, computed in one process."""
+    packed = [x[p.send_idx] for p, x in zip(plans, x_owns)]
+    offs = [torch.tensor([0] + p.send_splits).cumsum(0).tolist() for p in plans]
+    out = []
+    for p in plans:
+        parts = [packed[q][offs[q][p.rank]: offs[q][p.rank + 1]] for q in range(len(plans)) if q != p.rank]
+        out.append(torch.cat(parts) if parts else x_owns[p.rank][:0])
+    return out
+
+
+def local_reverse_exchange(plans: list[ShardPlan], g_ghosts: list[Tensor]) -> list[Tensor]:
+    """What reverse_exchange returns on every rank, computed in one process."""
+    offs = [torch.tensor([0] + p.recv_splits).cumsum(0).tolist() for p in plans]
+    out = []
+    for p in plans:
+        parts = [g_ghosts[q][offs[q][p.rank]: offs[q][p.rank + 1]] for q in range(len(plans)) if q != p.rank]
+        rows = torch.cat(parts) if parts else g_ghosts[p.rank][:0]
+        # rows arrive grouped by source rank in rank order, which is the layout of send_idx
+        out.append(_sum_by_owned_node(p, rows) if rows.shape[0] else rows.new_zeros((p.n_own, rows.shape[1])))
+    return out
 
 
 def run_sharded_layers(plan: ShardPlan, x_local: Tensor, n_layers: int, layer_fn, exchange_fn) -> Tensor:
@@ -195,6 +287,10 @@ def reduce_graph_outputs(partial: Tensor, group=None) -> Tensor:
     """Per-graph partial sums (B, out) of the owned nodes -> global result: one small all-reduce."""
     import torch.distributed as dist
 
+    if partial.is_cuda and dist.get_backend(group) == "gloo":     # CPU rehearsal of the RCCL path
+        out = partial.cpu()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out.to(partial.device)
     out = partial.clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     return out

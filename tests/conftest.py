@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session")
+def dev():
+    """cuda:0 with the HIP library loaded (-m gpu tests)."""
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from lcaonet_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
 def relerr(a, b) -> float:
     """max|a-b| / max|b|  — the per-tensor parity metric (SURVEY.md §7 hard part 2)."""
     a = torch.as_tensor(a).double().cpu()
