@@ -9,6 +9,18 @@ A step = one `model(batch)` forward (eval, fp32) over one resident batch: geomet
 L interaction layers (coefficient MLP + three-body + two-body + node scatter), output head.  Weak scaling: every
 rank owns its own batch of whole crystals (cells are independent graphs, so the data path has no collective);
 `value` = edges processed by all ranks / max-over-ranks time.  Prints ONE JSON line on rank 0.
+
+Other modes (never the driver's default):
+  --scaling strong          the SAME 1 000-crystal batch cut into N slices of whole crystals; each rank replays its slice
+                            as one HIP graph (lcaonet_amd.model.CapturedForward), so launch gaps do not grow with N
+  --workload cfg4           BASELINE config 4: ONE periodic crystal cut into N slabs of x-layers, one per rank; every rank
+                            builds only its slab (+ halo) and its plan (shard.plan_from_local), and runs
+                            LCAONet.forward_sharded: L-1 all-to-alls of boundary rows over RCCL per forward, overlapped
+                            with the owned-edge coefficient kernel, + one all-reduce of the per-graph sums.
+                            126^3 atoms at N = 8 (the config), 250 k atoms per GPU otherwise (--n-side overrides)
+  --emulate-world W         (N = 1) time rank --emulate-rank's slab of a W-way partition on this one GPU; its ghost rows
+                            come from a device-local stand-in
+LCAO_BENCH_REHEARSAL=1 runs every rank on cuda:0 over gloo (control-flow rehearsal on a one-GPU box; numbers meaningless).
 """
 from __future__ import annotations
 
@@ -39,6 +51,9 @@ WORKLOADS = {
     "cfg5-1of8": (dict(molecules=True, n_mol=16250, cutoff_graph=5.94),
                   dict(emb_size=256, emb_size_coeff=128, emb_size_conv=128, n_interaction=6, cutoff=6.0, max_z=10,
                        regress_forces=True, direct_forces=False)),
+    # BASELINE config 4, one crystal over all ranks (run_sharded_crystal); n_side is chosen from the number of ranks
+    "cfg4": (dict(sharded_crystal=True, a=3.2, sigma=0.05, cutoff_graph=5.94, max_neighbors=32, max_z=36),
+             dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=6.0)),
     "cfg2-small": (dict(n_cells=64, n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, max_z=36),
                    dict(emb_size=128, emb_size_coeff=128, emb_size_conv=128, n_interaction=3, cutoff=5.0)),
 }
@@ -108,6 +123,125 @@ def pmc_traffic(kernel: str):
 ROOFLINE_KERNELS = ("lcao_coeff_mlp_contract", "lcao_triplet_gemm", "lcao_triplet_sum")
 
 
+def forward_work_per_edge(model, n_nodes: int, n_edges: int) -> tuple[float, float]:
+    """ALGORITHMIC bytes and GEMM flops per edge of one whole forward (general per-edge cst, fp32, int32
+    indices; one HBM round trip wherever a stage needs other edges' results)."""
+    D, C, V, H, L = model.elec_info.n_orb, model.emb_size_coeff, model.emb_size_conv, model.emb_size, model.n_interaction
+    ne = n_nodes / max(n_edges, 1)
+    basis = 8 + 12 + ne * 12 + 4 + 12 + 4 * D
+    per_layer = 4.0 * (D * C + 3 * D * V + 2 * D + 2 * V + 5) + ne * 4.0 * (H + 2 * V + V + H)
+    flop_layer = 2.0 * D * (C * V + V * V) + 4.0 * V * V + 2.0 * (2 * V * V + V * V) + ne * (2.0 * H * 2 * V + 2.0 * V * H)
+    return basis + L * per_layer, L * flop_layer
+
+
+def roofline_forward(model, n_nodes: int, n_edges: int, seconds_per_forward: float) -> dict:
+    byts, flop = forward_work_per_edge(model, n_nodes, n_edges)
+    return {"note": "whole forward against both ceilings (SURVEY.md 8d): algorithmic bytes / flops per edge x E / t",
+            "bytes_per_edge": round(byts, 1), "gemm_flop_per_edge": round(flop, 1),
+            "hbm_frac": round(byts * n_edges / seconds_per_forward / (PEAK_HBM_GBS * 1e9), 4),
+            "mfma_frac": round(flop * n_edges / seconds_per_forward / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)}
+
+
+def run_strong(args, model, gen_kw, rank, world, dev, barrier, reduce_times):
+    """Strong scaling of config 2: the SAME batch (seed 1234) cut into `world` slices of whole crystals.  Each rank's
+    forward is one HIP-graph replay (index structures of the fixed edge list built once, outside the capture), so the
+    ~0.5 ms of launch gaps of the eager forward do not weigh more as the per-rank work shrinks."""
+    from lcaonet_amd.data.synthetic import jittered_cubic_cells
+    from lcaonet_amd.model import CapturedForward
+
+    n_cells = gen_kw["n_cells"]
+    c0, c1 = rank * n_cells // world, (rank + 1) * n_cells // world
+    batch = jittered_cubic_cells(seed=1234, device=dev, cell_range=(c0, c1), **gen_kw)
+    E, N = int(batch["edge_index"].shape[1]), int(batch["z"].numel())
+    step = CapturedForward(model, batch)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    elapsed_max, e_total = reduce_times(elapsed, E)
+    return {"metric": "edges/sec forward (LCAOConv stack), 1M-edge synthetic batch", "value": e_total * args.steps / elapsed_max,
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} strong: the {n_cells}-crystal batch of seed 1234 in {world} slices of whole "
+                                   f"crystals (rank 0: cells [{c0}, {c1}), N={N}, E={E}); whole forward replayed as one HIP graph "
+                                   "per rank (CSR of the fixed edge list built once outside the capture)",
+                       "edges_total": int(e_total), "sharding": "whole crystals per rank, no collective"},
+            "roofline_forward": roofline_forward(model, N, E, elapsed / args.steps)}
+
+
+def run_sharded_crystal(args, model, gen_kw, rank, world, dev, dist, barrier, reduce_times):
+    """BASELINE config 4: one crystal, one slab of x-layers per rank, LCAONet.forward_sharded over RCCL."""
+    from lcaonet_amd import shard
+    from lcaonet_amd.data.synthetic import jittered_cubic_crystal_slab
+
+    emu = args.emulate_world if world == 1 else 0
+    parts = emu or world
+    n_side = args.n_side or (126 if parts == 8 else int(round(63.0 * parts ** (1.0 / 3.0))))
+    ck = {k: v for k, v in gen_kw.items() if k != "sharded_crystal"}
+    t0 = time.perf_counter()
+    g, gid, n_own, owner_of = jittered_cubic_crystal_slab(n_side, args.emulate_rank if emu else rank, parts, seed=1234,
+                                                          device=dev, **ck)
+    plan = shard.plan_from_local(args.emulate_rank if emu else rank, parts, g, gid, n_own, owner_of, negotiate=not emu)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t0
+    H = model.emb_size
+    kw = {}
+    if emu:     # no peers exist: ghost rows from a local stand-in, partial sums kept as they are
+        ghost_rows = torch.randn(plan.n_ghost, H, device=dev)
+        kw = dict(exchange_fn=lambda x_own: ghost_rows, reduce_fn=lambda part: part)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model.forward_sharded(plan, **kw)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model.forward_sharded(plan, **kw)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    elapsed_max, e_total = reduce_times(elapsed, plan.e_own)
+    e_loc = int(plan.graph["edge_index"].shape[1])
+    stats = torch.tensor([plan.n_own, plan.n_ghost, plan.e_own, e_loc, plan.n_send, sum(1 for s in plan.send_splits if s)],
+                         dtype=torch.float64)
+    if dist is not None:
+        st = stats.clone() if rehearsal_cpu(dist) else stats.to(dev)
+        allst = [torch.zeros_like(st) for _ in range(world)]
+        dist.all_gather(allst, st)
+        allst = torch.stack([a.cpu() for a in allst])
+    else:
+        allst = stats.unsqueeze(0)
+    L = model.n_interaction
+    return {"metric": "edges/sec forward (LCAOConv stack), one crystal sharded by destination node", "value": e_total * args.steps / elapsed_max,
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg4: ONE periodic jittered {n_side}^3 = {n_side ** 3}-atom crystal, cutoff 6.0 (graph 5.94), "
+                                   f"<= 32 nearest neighbours, in {parts} slabs of x-layers"
+                                   + (f"; rank {args.emulate_rank} of {parts} EMULATED on one GPU (stand-in ghost rows)" if emu else "")
+                                   + f"; LCAONet(emb_size={H}, coeff={model.emb_size_coeff}, conv={model.emb_size_conv}, "
+                                   f"n_interaction={L}), eval, whole forward_sharded",
+                       "owned_edges_total": int(e_total), "sharding": "centre nodes by x-layer slab; halo in-edges replicated",
+                       "per_rank": {"n_own": allst[:, 0].tolist(), "n_ghost": allst[:, 1].tolist(), "e_own": allst[:, 2].tolist(),
+                                    "e_local": allst[:, 3].tolist(), "rows_sent_per_exchange": allst[:, 4].tolist(),
+                                    "peers": allst[:, 5].tolist()},
+                       "exchange": {"collective": "all_to_all_single, exact split sizes (RCCL)" if not emu else "stand-in",
+                                    "per_forward": L - 1, "bytes_sent_per_rank_per_exchange": (allst[:, 4] * H * 4).tolist(),
+                                    "overlap": "launched asynchronously; the next layer's owned-edge coefficient kernel runs under it"},
+                       "slab_and_plan_build_s_rank0": round(t_plan, 2),
+                       "peak_memory_GiB_rank0": round(torch.cuda.max_memory_allocated() / 2**30, 1)},
+            "roofline_forward": roofline_forward(model, plan.n_own, plan.e_own, elapsed / args.steps)}
+
+
+def rehearsal_cpu(dist) -> bool:
+    return dist.get_backend() == "gloo"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +250,10 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fused", type=int, default=-1, help="-1 auto, 0 generic kernels only, 1 force fused")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--n-side", type=int, default=0, help="cfg4: atoms per crystal edge (0 = 126 at 8 ranks, 250 k atoms per rank otherwise)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="cfg4 on ONE GPU: time one rank's slab of a W-way partition")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,6 +282,35 @@ def main():
 
     gen_kw, model_kw = WORKLOADS[args.workload]
     model = build_model(model_kw, 1234, dev)                      # identical weights on every rank
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_times(elapsed, units):
+        t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        if dist is None:
+            return elapsed, float(units)
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(tsum[1])
+
+    if gen_kw.get("sharded_crystal"):
+        line = run_sharded_crystal(args, model, gen_kw, rank, world, dev, dist, barrier, reduce_times)
+    elif args.scaling == "strong":
+        line = run_strong(args, model, gen_kw, rank, world, dev, barrier, reduce_times)
+    else:
+        line = None
+    if gen_kw.get("sharded_crystal") or args.scaling == "strong":
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if gen_kw.get("crystal"):
         from lcaonet_amd.data.synthetic import jittered_cubic_crystal
         ck = {k: v for k, v in gen_kw.items() if k != "crystal"}
@@ -157,12 +324,6 @@ def main():
     E = int(batch["edge_index"].shape[1])
     N = int(batch["z"].numel())
     fused = None if args.fused < 0 else bool(args.fused)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -182,15 +343,7 @@ def main():
         assert bool(torch.isfinite(out[1]).all())
         out = out[0]
     assert bool(torch.isfinite(out).all())
-    t = torch.tensor([elapsed, float(E)], dtype=torch.float64, device="cpu" if rehearsal else dev)
-    if dist is not None:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, e_total = float(tmax[0]), float(tsum[1])
-    else:
-        elapsed_max, e_total = elapsed, float(E)
+    elapsed_max, e_total = reduce_times(elapsed, E)
 
     # secondary measurements (rank 0 only, after the headline region and its reduction; a failure here is reported in
     # the line, it cannot take the headline down)

@@ -633,12 +633,12 @@ extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const in
 __device__ __forceinline__ float lcao_cutoff_grad(float r, float rc, int kind) {
   if (kind == LCAO_CUTOFF_NONE || !(r <= rc)) return 0.0f;
   const float x = r / rc;
+  const float om = 1.0f - x;   // factored like lcao_cutoff_eval: no cancellation towards rc
   if (kind == LCAO_CUTOFF_ENVELOPE) {
-    const float x4 = x * x * x * x;
-    return (-105.0f * x4 + 210.0f * x4 * x - 105.0f * x4 * x * x) / rc;   // d/dx (1 - 21x^5 + 35x^6 - 15x^7)
-  } else if (kind == LCAO_CUTOFF_POLYNOMIAL) {
     const float x2 = x * x;
-    return (-30.0f * x2 * x2 + 60.0f * x2 * x - 30.0f * x2) / rc;         // d/dx (1 - 6x^5 + 15x^4 - 10x^3)
+    return -105.0f * x2 * x2 * om * om / rc;   // d/dx (1 - 21x^5 + 35x^6 - 15x^7) = -105 x^4 (1 - x)^2
+  } else if (kind == LCAO_CUTOFF_POLYNOMIAL) {
+    return -30.0f * x * x * om * om / rc;      // d/dx (1 - 6x^5 + 15x^4 - 10x^3) = -30 x^2 (1 - x)^2
   }
   return -0.5f * sinf(r * 3.14159265358979323846f / rc) * 3.14159265358979323846f / rc;
 }

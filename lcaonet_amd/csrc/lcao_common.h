@@ -72,23 +72,29 @@ __device__ __forceinline__ float lcao_y_l0_grad(float c, int l) {
   }
 }
 
-// radial cutoff envelopes (lcaonet/nn/cutoff.py:32-34, 41-43, 62-67).  The envelope cancels catastrophically
-// towards rc, so its rounding pattern IS the result there: each power is a correctly rounded
-// pow (as torch's x**k), each product and sum is rounded separately (no FMA contraction), in the reference's order.
+// radial cutoff envelopes (lcaonet/nn/cutoff.py:32-34, 41-43, 62-67).  The reference's expanded forms cancel
+// catastrophically towards rc (1 - 21 x^5 + 35 x^6 - 15 x^7 has terms of 35 and a value of 3.5e-5 at
+// x = 0.99), so its fp32 result carries up to 7e-6 (of an orbital's maximum) of rounding noise against its own fp64 run.
+// Both polynomials have a triple root at x = 1; they are evaluated here in the factored, cancellation-free form
+//     1 - 21 x^5 + 35 x^6 - 15 x^7 = (1 - x)^3 (1 + 3x + 6x^2 + 10x^3 + 15x^4)          (EnvelopeCutoff, p = 5)
+//     1 -  6 x^5 + 15 x^4 - 10 x^3 = (1 - x)^3 (1 + 3x + 6x^2)                          (PolynomialCutoff)
+//     0.5 (cos(pi x) + 1)          = cos^2(pi x / 2)                                    (CosineCutoff)
+// which is within 3e-7 of the fp64 value everywhere, i.e. the distance to the reference's fp32 tables is the
+// reference's own noise (tests/test_gpu_parity.py::test_basis_kernels_vs_reference_tables, flat 1e-5 on the whole grid).
 __device__ __forceinline__ float lcao_cutoff_eval(float r, float rc, int kind) {
-#pragma clang fp contract(off)
   if (kind == LCAO_CUTOFF_NONE) return 1.0f;  // user-defined envelope applied by the caller
   if (!(r <= rc)) return 0.0f;
-  float x = r / rc;
+  const float x = r / rc;
+  const float om = 1.0f - x;
   if (kind == LCAO_CUTOFF_ENVELOPE) {
-    float t5 = -21.0f * powf(x, 5.0f), t6 = 35.0f * powf(x, 6.0f), t7 = -15.0f * powf(x, 7.0f);  // p = 5
-    return ((1.0f + t5) + t6) + t7;
+    const float q = (((15.0f * x + 10.0f) * x + 6.0f) * x + 3.0f) * x + 1.0f;
+    return om * om * om * q;
   } else if (kind == LCAO_CUTOFF_POLYNOMIAL) {
-    float t5 = 6.0f * powf(x, 5.0f), t4 = 15.0f * powf(x, 4.0f), t3 = 10.0f * (x * x * x);
-    return ((1.0f - t5) + t4) - t3;
+    const float q = (6.0f * x + 3.0f) * x + 1.0f;
+    return om * om * om * q;
   } else {
-    float a = r * 3.14159265358979323846f;
-    return 0.5f * (cosf(a / rc) + 1.0f);
+    const float c = cosf(1.57079632679489661923f * x);
+    return c * c;
   }
 }
 

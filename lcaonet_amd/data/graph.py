@@ -39,11 +39,13 @@ class Data:
     def to(self, *args, **kwargs):
         out = self.__class__()
         for k, v in self._store.items():
+            if k == "_num_graphs_memo":      # tied to one batch tensor (model/base.py::num_graphs)
+                continue
             out._store[k] = v.to(*args, **kwargs) if torch.is_tensor(v) else v
         return out
 
     def to_dict(self):
-        return dict(self._store)
+        return {k: v for k, v in self._store.items() if k not in ("_num_graphs_memo", "num_graphs")}
 
     def __repr__(self):
         items = ", ".join(f"{k}={tuple(v.shape) if torch.is_tensor(v) else v}" for k, v in self._store.items())
@@ -56,7 +58,7 @@ class Batch(Data):
         """Concatenate graphs the way PyG does: node-indexed keys (names containing 'index')
         are offset by the running node count and concatenated along the last dim."""
         out = cls()
-        keys = data_list[0].keys()
+        keys = [k for k in data_list[0].keys() if torch.is_tensor(data_list[0][k])]
         cols = {k: [] for k in keys}
         batch, n_off = [], 0
         for i, d in enumerate(data_list):
@@ -69,4 +71,5 @@ class Batch(Data):
         for k in keys:
             out[k] = torch.cat(cols[k], dim=-1 if "index" in k else 0)
         out["batch"] = torch.cat(batch)
+        out["num_graphs"] = len(data_list)
         return out

@@ -124,6 +124,7 @@ def make_graph(z: Tensor, pos: Tensor, lattice: Tensor, cutoff: float, batch: Te
     pbc = torch.ones(B, 3, dtype=torch.long, device=pos.device) if pbc is None else pbc.to(pos.device).long().reshape(B, 3)
     g = Batch(z=z, pos=pos.float().contiguous(), edge_index=ei.contiguous(), edge_shift=shift.contiguous(),
               lattice=lattice.contiguous(), batch=batch)
+    g["num_graphs"] = int(B)                                                  # PyG's Batch.num_graphs
     g[GraphKeys.PBC] = pbc                                                    # convert.py:168-169
     g[GraphKeys.Neighbors] = torch.bincount(batch[ei[0]], minlength=B)
     return g

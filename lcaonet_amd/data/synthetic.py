@@ -70,6 +70,7 @@ def _finish(pos, z, box, centre, neigh, shift, n_per_cell):
         edge_shift=shift.contiguous(),
         lattice=lattice.contiguous(),
         batch=torch.arange(B, device=pos.device).repeat_interleave(n_per_cell),
+        num_graphs=B,
     )
 
 
@@ -104,16 +105,21 @@ def random_periodic_cells(n_cells: int, n_atoms: int, box: float, cutoff_graph: 
 
 def jittered_cubic_cells(n_cells: int, n_side: int = 4, a: float = 3.2, sigma: float = 0.05,
                          cutoff_graph: float = 4.95, max_z: int = 36, seed: int = 1234,
-                         max_neighbors: int | None = None, device="cpu", dtype=torch.float32) -> Batch:
+                         max_neighbors: int | None = None, device="cpu", dtype=torch.float32,
+                         cell_range: tuple[int, int] | None = None) -> Batch:
     """BASELINE config 2/3 shape: `n_cells` cells, each a jittered n_side^3 simple-cubic lattice
     (spacing `a`, gaussian jitter sigma*a), z ~ U{1..max_z}.  n_cells=1000, n_side=4, a=3.2,
-    cutoff 4.95 gives N=64 000 and about 1.15 M edges (about 18 neighbours)."""
+    cutoff 4.95 gives N=64 000 and about 1.15 M edges (about 18 neighbours).
+    cell_range = (c0, c1): only cells [c0, c1) of that batch (strong scaling: every rank a slice of the SAME batch)."""
     g = torch.Generator().manual_seed(seed)
     n = n_side**3
     r = torch.arange(n_side, dtype=torch.float64)
     grid = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1).reshape(1, n, 3) * a
     pos = grid + torch.randn(n_cells, n, 3, generator=g, dtype=torch.float64) * (sigma * a)
     z = torch.randint(1, max_z + 1, (n_cells, n), generator=g)
+    if cell_range is not None:
+        pos, z = pos[cell_range[0]: cell_range[1]], z[cell_range[0]: cell_range[1]]
+        n_cells = pos.shape[0]
     pos = pos.to(dtype).to(device)
     z = z.to(device)
     bx = torch.full((n_cells, 3), n_side * a, dtype=dtype, device=device)

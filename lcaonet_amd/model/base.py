@@ -7,6 +7,27 @@ from .. import ops
 from ..data.keys import GraphKeys
 
 
+def num_graphs(graph, batch_idx) -> int | None:
+    """B = batch.max() + 1 (reference lcaonet.py:292) without stalling the stream on every call: PyG's `Batch.num_graphs`
+    when the graph object carries one (the containers of lcaonet_amd.data do), else ONE `batch.max().item()` whose
+    result is remembered in the graph for as long as it holds the same batch tensor."""
+    if batch_idx is None:
+        return None
+    n = getattr(graph, "num_graphs", None)
+    if isinstance(n, int):
+        return n
+    memo = graph.get("_num_graphs_memo") if hasattr(graph, "get") else None
+    tag = (batch_idx.data_ptr(), batch_idx._version, batch_idx.numel())
+    if memo is not None and memo[0] == tag:
+        return memo[1]
+    n = int(batch_idx.max().item()) + 1 if batch_idx.numel() else 0
+    try:
+        graph["_num_graphs_memo"] = (tag, n)
+    except Exception:  # noqa: BLE001  (a read-only container: pay the sync each call)
+        pass
+    return n
+
+
 class BaseMPNN(nn.Module):
     def __init__(self) -> None:
         super().__init__()

@@ -170,7 +170,7 @@ def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
     tables = (x_tab (max_z+1, H), cst_pair, zdim): embedding tables supplied by the caller (model/train.py: train-mode
     BatchNorm batch statistics) instead of the eval-mode ones."""
     from .lcaonet import EdgeContext
-    from .base import BaseMPNN
+    from .base import BaseMPNN, num_graphs
 
     _check_supported(model, tables is not None)
     batch_idx = graph.get(GraphKeys.Batch_idx)
@@ -203,8 +203,7 @@ def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
     pre_b = ops.dense(a, lin[2].weight.detach(), lin[2].bias.detach())
     b = torch.nn.functional.silu(pre_b)
     prop = ops.dense(b, lin[4].weight.detach())
-    lat = graph.get(GraphKeys.Lattice)
-    n_graphs = lat.shape[0] if (batch_idx is not None and lat is not None and lat.dim() == 3) else None
+    n_graphs = num_graphs(graph, batch_idx)
     red = "sum" if model.out_layer.is_extensive else "mean"
     if batch_idx is not None:
         out = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce=red)

@@ -20,6 +20,7 @@ cat[x_s, x_t] = x_s W_a^T + x_t W_b^T.
 """
 from __future__ import annotations
 
+import warnings
 from collections.abc import Callable
 from dataclasses import dataclass
 
@@ -38,7 +39,7 @@ from ..nn.rbf import BaseRadialBasis
 from ..nn.scatter import csr_ptr, scatter
 from ..nn.shbf import SphericalHarmonicsBasis
 from ..utils.resolve import activation_resolver, cutoffnet_resolver, init_resolver, rbf_resolver
-from .base import BaseMPNN
+from .base import BaseMPNN, num_graphs
 
 
 @dataclass
@@ -115,6 +116,11 @@ class LCAOEmbedding(nn.Module):
         this module is a function of the atomic number (x) or of the (z_s, z_t) pair (cst), so the MLPs run on max_z
         rows:  cst = bn(fe[z_t] * (1 + f_z([zc[z_s], zc[z_t]])))  (embed.py:246-249)."""
         assert not self.training
+        # weights only (no input reaches these tables): kept until a parameter or buffer of this module changes
+        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        cached = self.__dict__.get("_species")
+        if cached is not None and cached[0] == key:
+            return cached[1]
         zz = torch.arange(1, self.max_z + 1, device=dev)
         z_embed = self.z_embed(zz)
         node_z, coeff_z = torch.split(z_embed, [self.emb_size, self.emb_size_coeff], dim=-1)
@@ -127,16 +133,16 @@ class LCAOEmbedding(nn.Module):
             x_tab = self.node_embed(node_z.contiguous())
         C = self.emb_size_coeff
         ce = self.coeff_embed
-        wz = ce.f_z[0].weight.detach()
-        coeff_z = coeff_z.contiguous()
-        U = ops.dense(coeff_z, wz[:, :C].contiguous())   # centre half of f_z
-        Vt = ops.dense(coeff_z, wz[:, C:].contiguous())  # neighbour half
+        U, Vt = ce.node_halves(coeff_z.contiguous())      # centre / neighbour half of f_z
         FE = run_mlp(ce.f_e, coeff_e.contiguous())        # (max_z, D, C)
         bn = ce.bn
         scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias.detach() - bn.running_mean * scale
         pad = lambda t: torch.cat([torch.zeros_like(t[:1]), t], dim=0).contiguous()
-        return dict(x=pad(x_tab), FE=pad(FE), U=pad(U), Vt=pad(Vt), scale=scale.contiguous(), shift=shift.contiguous())
+        tables = dict(x=pad(x_tab), FE=pad(FE), U=pad(U), Vt=pad(Vt), scale=scale.contiguous(), shift=shift.contiguous())
+        if not torch.cuda.is_current_stream_capturing():     # a capture must record the kernels that fill its own copy
+            self.__dict__["_species"] = (key, tables)
+        return tables
 
     @torch.no_grad()
     def forward_species(self, z: Tensor, ctx: EdgeContext) -> tuple[Tensor, Tensor]:
@@ -237,7 +243,8 @@ class LCAOInteraction(nn.Module):
         WsT = Ws.t().contiguous()
         w_cat = torch.cat([Wk, ops.dense(WsT, Wa).t(), ops.dense(WsT, Wb).t()], dim=0).contiguous()
         b_cat = torch.cat([bk, ops.dense(bs.unsqueeze(0), Wa, b1)[0], ops.dense(bs.unsqueeze(0), Wb)[0]]).contiguous()
-        self.__dict__["_fold"] = (key, w_cat, b_cat)
+        if not torch.cuda.is_current_stream_capturing():   # tensors made inside a capture live in the graph's pool
+            self.__dict__["_fold"] = (key, w_cat, b_cat)
         return w_cat, b_cat
 
     def _node_level(self, x: Tensor, gate: Tensor, Ps: Tensor | None, Pt: Tensor) -> None:
@@ -532,11 +539,26 @@ class LCAONet(BaseMPNN):
         precision: "fp32" (default; exact fp32 MFMA) or "bf16x3" (BASELINE config 3: the per-edge coefficient GEMMs on
         bf16 MFMA with two-term operand splitting; ~1e-5 from fp32 where plain bf16 would be 4e-3).
 
-        differentiable (default: `self.training and torch.is_grad_enabled()`): record an autograd graph to every
-        parameter (model/train.py: HIP forward + hand-written HIP backward of the interaction stack).  Otherwise the
-        inference pipeline runs and the result carries no graph."""
+        differentiable (default: autograd is enabled and some parameter requires grad — what the reference does in
+        train AND eval mode, lcaonet.py:488-540): record an autograd graph to every parameter (model/train.py: HIP
+        forward + hand-written HIP backward of the interaction stack; autograd forces then carry a graph as with the
+        reference's create_graph=True).  Otherwise — under torch.no_grad(), with frozen parameters, with
+        differentiable=False, or when an inference-only option (fused, trace, exact_norm, cst_mode, precision,
+        edge_context, materialize_triplets) is given — the inference pipeline runs and the result carries no graph."""
         if differentiable is None:
-            differentiable = self.training and torch.is_grad_enabled()
+            inference_only = (fused is not None or materialize_triplets or trace is not None or exact_norm
+                              or cst_mode != "edge" or precision != "fp32" or edge_context is not None)
+            differentiable = (torch.is_grad_enabled() and not inference_only
+                              and any(p.requires_grad for p in self.parameters()))
+            if differentiable and not self.training:
+                from .train import unsupported_reason
+
+                why = unsupported_reason(self)
+                if why is not None:   # eval mode: serve the call, say that the result is graph-less
+                    warnings.warn(f"LCAONet.forward: {why}; running the inference pipeline (the result carries no "
+                                  "autograd graph).  Pass differentiable=False or use torch.no_grad() to silence.",
+                                  stacklevel=2)
+                    differentiable = False
         if differentiable:
             from .train import forward_differentiable
 
@@ -552,6 +574,7 @@ class LCAONet(BaseMPNN):
         ValenceMask.forward(z, idx_t))."""
         return self.valence_mask.valence[:zdim].to(torch.float32).repeat(zdim, 1).contiguous()
 
+    @torch.no_grad()
     def _forward_inference(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
                            trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
                            precision: str = "fp32", edge_context: EdgeContext | None = None):
@@ -603,9 +626,6 @@ class LCAONet(BaseMPNN):
                 trace[f"x{i + 1}"] = x
                 trace[f"three_body_w{i + 1}"] = tr["three_body_w"]
 
-        n_graphs = None
-        if batch_idx is not None:
-            lat = graph.get(GraphKeys.Lattice)
-            n_graphs = lat.shape[0] if (lat is not None and lat.dim() == 3) else None  # avoids batch.max().item()
+        n_graphs = num_graphs(graph, batch_idx)      # B = batch.max() + 1 as lcaonet.py:292, without a per-call sync
         out = self.out_layer(x, batch_idx, idx_s, idx_t, uvec, pos, n_graphs)
         return self.pp_layer(out, z, batch_idx, n_graphs)

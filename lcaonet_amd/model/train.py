@@ -278,14 +278,22 @@ class LCAOStackFn(torch.autograd.Function):
         return (None, None, g_x_tab.reshape(fctx.x_tab_shape), *g_Tf, *g_params)
 
 
+def unsupported_reason(model) -> str | None:
+    """Why the differentiable path cannot serve this model, or None."""
+    for layer in model.int_layers:
+        if not all(type(layer.f_node[k]) is nn.SiLU for k in (1, 3)):
+            return "the differentiable path is built for the default SiLU activation"
+    return None
+
+
 def forward_differentiable(model, graph, update_stats: bool = True, energy_only: bool = False):
     """LCAONet.forward with an autograd graph to every parameter (training).  Same outputs as the inference path.
     energy_only: return the (B, out) property alone (no force head); update_stats as species_tables_autograd."""
     if model.regress_forces and not model.direct_forces and not energy_only:
         return forward_force_training(model, graph)
-    for layer in model.int_layers:
-        if not all(type(layer.f_node[k]) is nn.SiLU for k in (1, 3)):
-            raise NotImplementedError("the differentiable path is built for the default SiLU activation")
+    why = unsupported_reason(model)
+    if why is not None:
+        raise NotImplementedError(why)
     z = graph[GraphKeys.Z]
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(graph[GraphKeys.Pos], "graph.pos")
@@ -310,8 +318,8 @@ def forward_differentiable(model, graph, update_stats: bool = True, energy_only:
     ol = model.out_layer
     prop = _mlp(ol.out_lin, x)
     if batch_idx is not None:
-        lat = graph.get(GraphKeys.Lattice)
-        B = lat.shape[0] if (lat is not None and lat.dim() == 3) else int(batch_idx.max().item()) + 1
+        from .base import num_graphs
+        B = num_graphs(graph, batch_idx)
         out = torch.zeros(B, prop.shape[1], device=prop.device).index_add_(0, batch_idx, prop)
         cnt = torch.zeros(B, device=prop.device).index_add_(0, batch_idx, torch.ones_like(batch_idx, dtype=prop.dtype))
         if not ol.is_extensive:

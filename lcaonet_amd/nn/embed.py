@@ -14,6 +14,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ..atomistic.info import ElecInfo
+from .. import ops
 from .base import Dense, run_mlp
 
 
@@ -83,51 +84,61 @@ class ValenceMask(nn.Module):
 
 
 class EmbedNode(nn.Module):
+    """Initial node state: BatchNorm(MLP([z vector | orbital-pooled electron vector])) — reference embed.py:136-194
+    (parameter names `f_enc.{0,2}`, `bn` are the checkpoint contract).  The electron vectors of the D orbitals are pooled
+    as sum / sqrt(D).  At inference the whole module is evaluated on max_z rows and gathered
+    (LCAOEmbedding.species_tables)."""
+
     def __init__(self, emb_size: int, emb_size_z: int, use_elec: bool, emb_size_e: int | None = None,
                  activation: nn.Module = nn.SiLU(), weight_init: Callable[[Tensor], Tensor] | None = None):
         super().__init__()
-        self.emb_size = emb_size
-        self.emb_size_z = emb_size_z
-        self.use_elec = use_elec
-        if use_elec:
-            assert emb_size_e is not None
-            self.emb_size_e = emb_size_e
-        else:
-            self.emb_size_e = 0
-        hid_size = max(emb_size, (emb_size_z + self.emb_size_e) // 2)
-        self.f_enc = nn.Sequential(
-            Dense(emb_size_z + self.emb_size_e, hid_size, True, weight_init), activation,
-            Dense(hid_size, emb_size, True, weight_init), activation,
-        )
+        if use_elec and emb_size_e is None:
+            raise ValueError("emb_size_e is required when use_elec is True")
+        self.emb_size, self.emb_size_z, self.use_elec = emb_size, emb_size_z, use_elec
+        self.emb_size_e = emb_size_e if use_elec else 0
+        width_in = emb_size_z + self.emb_size_e
+        hidden = max(emb_size, width_in // 2)
+        self.f_enc = nn.Sequential(Dense(width_in, hidden, True, weight_init), activation,
+                                   Dense(hidden, emb_size, True, weight_init), activation)
         self.bn = nn.BatchNorm1d(emb_size)
 
+    def encoder_input(self, z_emb: Tensor, e_emb: Tensor | None) -> Tensor:
+        if not self.use_elec:
+            return z_emb
+        if e_emb is None:
+            raise ValueError("e_emb must be set when use_elec is True.")
+        pooled = torch.div(e_emb.sum(dim=1), math.sqrt(e_emb.shape[1]))
+        return torch.cat([z_emb, pooled], dim=-1)
+
     def forward(self, z_emb: Tensor, e_emb: Tensor | None = None) -> Tensor:
-        if self.use_elec:
-            if e_emb is None:
-                raise ValueError("e_emb must be set when use_elec is True.")
-            e_emb = e_emb.sum(1) / math.sqrt(e_emb.shape[1])
-            z_e_emb = torch.cat([z_emb, e_emb], dim=-1)
-        else:
-            z_e_emb = z_emb
-        return self.bn(run_mlp(self.f_enc, z_e_emb))
+        return self.bn(run_mlp(self.f_enc, self.encoder_input(z_emb, e_emb)))
 
 
 class EmbedCoeffs(nn.Module):
+    """Per-edge coefficient vectors cst (E, D, C) = BatchNorm(fe[t] + fe[t] * f_z([zc[s] | zc[t]])) — reference
+    embed.py:197-249 (parameter names `f_z.0`, `f_e.{0,2}`, `bn`).  f_z is linear and bias-free, so it is applied to the
+    N node rows as two half-width products (centre half, neighbour half) that are then added per edge, instead of to E
+    concatenated rows — the same split lcao_embed_coeffs uses on the per-species tables."""
+
     def __init__(self, emb_size: int, emb_size_z: int, emb_size_e: int, n_orb: int,
                  activation: nn.Module = nn.SiLU(), weight_init: Callable[[Tensor], Tensor] | None = None):
         super().__init__()
-        self.emb_size = emb_size
-        self.emb_size_z = emb_size_z
-        self.emb_size_e = emb_size_e
+        self.emb_size, self.emb_size_z, self.emb_size_e = emb_size, emb_size_z, emb_size_e
         self.f_z = nn.Sequential(Dense(2 * emb_size_z, emb_size, False, weight_init))
-        self.f_e = nn.Sequential(
-            Dense(emb_size_e, emb_size, False, weight_init), activation,
-            Dense(emb_size, emb_size, False, weight_init), activation,
-        )
+        self.f_e = nn.Sequential(Dense(emb_size_e, emb_size, False, weight_init), activation,
+                                 Dense(emb_size, emb_size, False, weight_init), activation)
         self.bn = nn.BatchNorm1d(emb_size * n_orb)
 
+    def node_halves(self, z_emb: Tensor) -> tuple[Tensor, Tensor]:
+        """(N, C) contributions of a node to f_z as the centre / as the neighbour of an edge."""
+        w = self.f_z[0].weight.detach()
+        k = self.emb_size_z
+        return ops.dense(z_emb, w[:, :k].contiguous()), ops.dense(z_emb, w[:, k:].contiguous())
+
     def forward(self, z_emb: Tensor, e_emb: Tensor, idx_s: Tensor, idx_t: Tensor) -> Tensor:
-        z_emb = run_mlp(self.f_z, torch.cat([z_emb[idx_s], z_emb[idx_t]], dim=-1))
-        e_emb = run_mlp(self.f_e, e_emb)[idx_t]
-        coeff_emb = e_emb + e_emb * z_emb.unsqueeze(1)
-        return self.bn(coeff_emb.reshape(coeff_emb.size(0), -1)).reshape(coeff_emb.size())
+        as_centre, as_neigh = self.node_halves(z_emb)
+        zz = as_centre[idx_s] + as_neigh[idx_t]                           # (E, C)
+        orb = run_mlp(self.f_e, e_emb)[idx_t]                             # (E, D, C): the neighbour's orbital vectors
+        raw = torch.addcmul(orb, orb, zz.unsqueeze(1))
+        n_edges, n_orb, width = raw.shape
+        return self.bn(raw.view(n_edges, n_orb * width)).view(n_edges, n_orb, width)

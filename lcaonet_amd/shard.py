@@ -152,11 +152,13 @@ def _a2a(out: Tensor, inp: Tensor, out_splits, in_splits, group=None, async_op: 
 
 
 def plan_from_local(rank: int, world: int, graph: Data, node_gid: Tensor, n_own: int, owner_of, n_graphs: int = 1,
-                    group=None) -> ShardPlan:
+                    group=None, negotiate: bool = True) -> ShardPlan:
     """A rank's plan from its OWN slab: `graph` holds the owned nodes first ([0, n_own)) then the ghosts in any order,
     with every owned out-edge and every in-edge of an owned node; `node_gid` (n_local) are global ids and
     `owner_of(gids) -> ranks` names their owners.  Ghosts are renumbered by (owner, global id) and the send lists come
-    from two plan-time all-to-alls (counts, then the requested ids) — collective: every rank of `group` must call."""
+    from two plan-time all-to-alls (counts, then the requested ids) — collective: every rank of `group` must call.
+    negotiate=False (timing ONE rank's share without its peers, bench.py --emulate-world): no collective, empty send
+    lists; the caller supplies the ghost rows itself (forward_sharded(exchange_fn=...))."""
     dev = node_gid.device
     n_loc = int(node_gid.numel())
     ghost_gid = node_gid[n_own:]
@@ -174,14 +176,12 @@ def plan_from_local(rank: int, world: int, graph: Data, node_gid: Tensor, n_own:
     g[GraphKeys.Edge_idx] = ei.contiguous()
     ghost_gid, ghost_owner = ghost_gid[o], ghost_owner[o]
     recv_cnt = torch.bincount(ghost_owner, minlength=world) if o.numel() else torch.zeros(world, dtype=torch.long, device=dev)
-    send_cnt = torch.empty_like(recv_cnt)
-    if world > 1:
+    send_cnt = torch.zeros_like(recv_cnt)
+    if world > 1 and negotiate:
         _a2a(send_cnt, recv_cnt, None, None, group)
-    else:
-        send_cnt.copy_(recv_cnt)
     recv_splits, send_splits = [int(c) for c in recv_cnt.tolist()], [int(c) for c in send_cnt.tolist()]
     req = torch.empty(sum(send_splits), dtype=torch.long, device=dev)
-    if world > 1:
+    if world > 1 and negotiate:
         _a2a(req, ghost_gid.contiguous(), send_splits, recv_splits, group)     # ids the peers want from me
     own_gid = node_gid[:n_own]
     srt = torch.argsort(own_gid)

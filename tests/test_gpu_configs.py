@@ -167,6 +167,6 @@ def test_radial_basis_flat_tolerance_inside_095_rc(golden_loader, dev, rc, cut):
     ei = ElecInfo(96, None, None, 1)
     rb = HydrogenRadialBasis(rc, ei, cutoffnet_resolver(cut, cutoff=rc)).to(dev)(r.to(dev)).cpu()
     ref = torch.from_numpy(z[f"hydrogen_{cut}_rc{rc:g}_f32"])
-    assert ei.n_orb == 18 and int(keep.sum()) > 3000
+    assert ei.n_orb == 18 and int(keep.sum()) > 300          # 331 of the 384 grid points
     for d in range(ei.n_orb):
         assert relerr(rb[keep, d], ref[keep, d]) <= TOL, (d, relerr(rb[keep, d], ref[keep, d]))

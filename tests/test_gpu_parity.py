@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def _model_from_golden(g: Golden, dev):
+def _model_from_golden(g: Golden, dev, grad=False):
+    """grad=False: parameters frozen, so a plain m(graph) runs the inference pipeline (LCAONet.forward records an
+    autograd graph whenever autograd is on and a parameter requires grad, like the reference)."""
     from lcaonet_amd.model import LCAONet
     kw = {k: v for k, v in g.cfg.items() if k != "training"}
     for k in ("atomref", "mean"):
@@ -23,7 +25,7 @@ def _model_from_golden(g: Golden, dev):
     m = LCAONet(**kw)
     m.load_state_dict(g.state_dict(), strict=True)
     m.train(bool(g.cfg.get("training", False)))
-    return m.to(dev)
+    return m.to(dev).requires_grad_(grad)
 
 
 def _graph(g: dict, dev):
@@ -56,14 +58,14 @@ def test_basis_kernels_vs_reference_tables(golden_loader, dev, rc, cut):
     ref = torch.from_numpy(z[f"hydrogen_{cut}_rc{rc:g}_f32"])
     ref64 = torch.from_numpy(z[f"hydrogen_{cut}_rc{rc:g}_f64"])
     for d in range(ei.n_orb):  # per orbital (columns span many orders of magnitude)
-        # the grid runs up to rc, i.e. through the shell where the envelope cancels: there two fp32 evaluations
-        # can only agree to the reference's own fp32-vs-fp64 noise (7e-6 of the column maximum for 4f / 5f at
-        # r = 0.96 rc; measured in gpurun_out/diag.log), so the bound is max(1e-5, 2 x that noise)
+        # flat 1e-5 on the WHOLE grid, the envelope-cancellation shell up to rc included: the kernel evaluates the
+        # cutoff in factored form (csrc/lcao_common.h), so what separates it from the reference's fp32 table is the
+        # reference's own fp32-vs-fp64 noise (<= 7e-6 of the column maximum, 4f / 5f near 0.96 rc)
         noise = relerr(ref[:, d], ref64[:, d])
         e32 = relerr(rb[:, d], ref[:, d])
-        assert e32 <= max(TOL, 2 * noise), (d, e32, noise)
-        # and no worse against the fp64 truth than the reference's own fp32 run is (x2 slack)
-        assert relerr(rb[:, d], ref64[:, d]) <= 2 * noise + 1e-6
+        assert e32 <= TOL, (d, e32, noise)
+        # and closer to the fp64 truth than the reference's own fp32 run is
+        assert relerr(rb[:, d], ref64[:, d]) <= max(0.5 * noise, 1e-6), (d, relerr(rb[:, d], ref64[:, d]), noise)
     sb = SphericalBesselRadialBasis(rc, ei, cn).to(dev)(r)
     assert relerr(sb, z[f"bessel_{cut}_rc{rc:g}_f32"]) <= TOL
     c = torch.from_numpy(z["costheta"]).float().to(dev)
@@ -165,7 +167,7 @@ def test_model_vs_reference_golden(golden_loader, dev, name):
     with torch.no_grad():   # inference pipeline (in train mode: BatchNorm batch statistics through the module path)
         out = m(_graph(g.graph(), dev), trace=tr)
     if m.training:          # the differentiable (training) path gives the same values from species-table statistics
-        m2 = _model_from_golden(g, dev)
+        m2 = _model_from_golden(g, dev, grad=True)
         out_d = m2(_graph(g.graph(), dev))
         assert out_d.requires_grad and relerr(out_d.detach(), g.ref("out")) <= TOL
     force = None
@@ -197,7 +199,8 @@ def test_autograd_forces_vs_reference_golden(golden_loader, dev):
     assert relerr(force, g.ref("force")) <= 5 * TOL    # a derivative: one order looser than the values
 
 
-def _random_model(dev, seed, **kw):
+def _random_model(dev, seed, grad=False, **kw):
+    """grad=False: frozen parameters = the inference pipeline (see _model_from_golden)."""
     from lcaonet_amd.model import LCAONet
     torch.manual_seed(seed)
     m = LCAONet(**kw).eval()
@@ -208,8 +211,8 @@ def _random_model(dev, seed, **kw):
             mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) + 0.5)
         if isinstance(mod, torch.nn.Linear) and mod.bias is not None:
             mod.bias.data.copy_(0.1 * torch.randn(mod.bias.shape, generator=gen))
-    sd = {k: v.clone() for k, v in m.state_dict().items()}
-    return m.to(dev), sd
+    sd = {k: v.clone().detach() for k, v in m.state_dict().items()}
+    return m.to(dev).requires_grad_(grad), sd
 
 
 def _oracle_run(sd, kw, graph_cpu, dtype=torch.float32):
@@ -663,7 +666,7 @@ def test_parameter_gradients_vs_oracle_autograd(dev, width, training, valence):
     from lcaonet_amd.data.synthetic import random_periodic_cells
     kw = dict(emb_size=32, emb_size_coeff=width, emb_size_conv=width, n_interaction=2, cutoff=5.0, out_size=2,
               add_valence=valence)
-    m, sd = _random_model(dev, 400 + width, **kw)
+    m, sd = _random_model(dev, 400 + width, grad=True, **kw)
     m.train(training)
     g = random_periodic_cells(3, 12, 6.0, 0.99 * 5.0, seed=21)
     proj = torch.randn(3, 2, generator=torch.Generator().manual_seed(1))
@@ -792,7 +795,7 @@ def test_force_training_central_difference_vs_oracle_double_backward(dev, traini
     from lcaonet_amd.data.synthetic import random_periodic_cells
     kw = dict(emb_size=32, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=5.0, regress_forces=True,
               direct_forces=False)
-    m, sd = _random_model(dev, 555, **kw)
+    m, sd = _random_model(dev, 555, grad=True, **kw)
     m.train(training)
     g = random_periodic_cells(2, 10, 6.0, 0.99 * 5.0, seed=31)
     cfg = _ocfg({**kw, "rbf_type": "hydrogen", "training": training})
