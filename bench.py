@@ -358,7 +358,7 @@ def main():
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t1) / args.steps, err
 
-    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = None
+    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = mat_ms = mat_err = None
     secondary_error = None
     kall = {}
     if rank == 0:
@@ -368,6 +368,7 @@ def main():
                     model(batch, fused=fused)
                 kall = prof_all.summary()
             if not with_forces:   # the force workloads already run on the pair table; no secondary modes there
+                mat_ms, mat_err = timed(cst_mode="edge_tensor")              # cst materialised per edge as the reference holds it
                 pair_ms, pair_err = timed(cst_mode="pair")                   # species-pair table
                 bf_ms, bf_err = timed(precision="bf16x3")                    # BASELINE config 3
                 bp_ms, bp_err = timed(precision="bf16x3", cst_mode="pair")
@@ -463,14 +464,24 @@ def main():
             "config": {"workload": f"{args.workload}: {shape} per GPU (N={N}, E={E} per GPU), graph cutoff "
                                    f"{gen_kw['cutoff_graph']}, "
                                    f"LCAONet(emb_size={model.emb_size}, coeff={C}, conv={V}, n_interaction={L}, D={D}, "
-                                   f"cutoff={model.cutoff}), random-init weights, eval, whole forward"
+                                   f"cutoff={model.cutoff}), random-init weights, eval, whole forward; general per-edge "
+                                   "coefficient MLP (every (edge, orbital) row through both f_coeffs layers), its input rows "
+                                   "gathered from the (z_s, z_t) table inside the kernel instead of a materialised (E,D,C) tensor"
                                    + (" + forces = -dE/dpos (reverse sweep)" if with_forces else ""),
                        "edges_per_gpu": E, "nodes_per_gpu": N, "sharding": "whole crystals per rank, no collective"},
             "roofline": roof, "roofline_hbm": roof_hbm,
+            "roofline_forward": roofline_forward(model, N, E, elapsed_max / args.steps),
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kall.items(), key=lambda kv: -kv[1][1])},
             "kernel_ms_per_step_note": "separate pass after the timed region with every C-ABI call bracketed by HIP events",
             "kernel_rooflines": per_kernel,
         }
+        if mat_ms is not None:
+            line["materialized_cst_mode"] = {
+                "note": "NOT the headline: cst_mode='edge_tensor' — the (E, D, C) coefficient tensor written by lcao_embed_coeffs "
+                        "and re-read by every layer, as the reference holds it (the headline gathers the same rows from the "
+                        "species-pair table inside lcao_coeff_mlp_contract; same flops, same outputs)",
+                "ms_per_step_rank0": round(mat_ms, 3), "edges_per_s_rank0": E / (mat_ms * 1e-3),
+                "max_rel_diff_vs_headline_output": mat_err}
         if pair_ms is not None:
             line["pair_table_mode"] = {
                 "note": "NOT the headline: LCAONet.forward(cst_mode='pair') — f_coeffs evaluated on the (z_s,z_t) species-pair "

@@ -162,22 +162,31 @@ int lcao_triplet_literal(const float* cstf, const float* rb, const float* shb, c
 
 /* lcaonet.py:170 + the contraction above in ONE kernel: f_coeffs = SiLU(SiLU(cst W1^T) W2^T) is never
  * written to HBM.  cst (E, D, C) orig order; W1 (V, C); W2 (Vt, V).  fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * cst_row (nullable): int32 (E) in p-space — edge p reads row cst_row[p] of `cst` instead of row order[p]: the
+ * gather of the coefficient rows fused into the kernel (e.g. cst = the (zdim^2, D, C) species-pair table of
+ * LCAOEmbedding and cst_row[p] = z_s * zdim + z_t, so the (E, D, C) tensor is never materialised; every (edge, orbital)
+ * row still runs through both layers).
  * Outputs (p-space): B (E,V) [, Bv (E,V) with valence];  and EITHER the raw A (E,n_l,V) (Ag == NULL)
  * OR, for lcao_triplet_gemm, the gated copy Ag[p,l,:] = A[p,l,:] * gate[src_p[p],:] plus the per-edge Gram
  * matrix gram[p, 10] (upper triangle of A A^T over l, l' <= 3, row-major; ungated).  A is scratch when valence. */
-int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
-                            const float* valence_ed /* (E,D) orig order, nullable */, const float* W1,
+int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+                            const int32_t* l_of_d, const float* valence_ed /* (E,D) orig order, nullable */, const float* W1,
                             const float* W2, const float* gate /* (N,V) sigmoid(xk), nullable */,
                             const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, int valence,
                             float* A, float* B, float* Bv, float* Ag, float* gram,
                             void* workspace /* device, >= 8 bytes: tile-queue counters, zeroed by the call */,
                             size_t ws_bytes, void* stream);
 
+/* cst_row for the call above when cst is LCAOEmbedding's species-pair table: row[p] = z[src_p[p]] * zdim + z[dst_p[p]]
+ * (embed.py:246-249: cst[e] depends on the two atomic numbers only). */
+int lcao_pair_rows(const int64_t* z, const int32_t* src_p, const int32_t* dst_p, int64_t n_edges, int zdim, int32_t* row,
+                   void* stream);
+
 /* BASELINE config 3: the same fused kernel with both Dense layers on bf16 MFMA, every fp32 operand split into two
  * bf16 terms and each product run as three MFMAs with fp32 accumulation ("bf16x3": 6-9e-6 relative error on the MLP,
  * against 3.6e-3 for plain bf16).  No valence.  workspace >= 4 bytes. */
-int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
-                                   const float* W1, const float* W2, const float* gate, const int32_t* src_p,
+int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+                                   const int32_t* l_of_d, const float* W1, const float* W2, const float* gate, const int32_t* src_p,
                                    int64_t n_edges, int n_orb, int C, int V, int n_l, float* A, float* B, float* Ag,
                                    float* gram, void* workspace, size_t ws_bytes, void* stream);
 

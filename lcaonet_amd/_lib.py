@@ -27,6 +27,7 @@ SIGNATURES = {
     "lcao_nl_bin_sort": [P, P, P, L, L, P, P, P, P, P, c_size_t, P],
     "lcao_nl_search": [P, P, P, P, P, P, L, F, I, P, P, P, P, P, P, P],
     "lcao_dense": [P, L, P, P, P, L, P, L, L, I, I, I, P],
+    "lcao_pair_rows": [P, P, P, L, I, P, P],
     "lcao_node_tables": [P, P, P, L, I, I, P, P, P, P],
     "lcao_segment_sum": [P, P, P, L, I, P, P],
     "lcao_segment_sum_gather": [P, P, P, L, I, P, P],
@@ -38,8 +39,8 @@ SIGNATURES = {
     "lcao_pair_silu": [P, P, P, P, L, I, P, P],
     "lcao_embed_coeffs": [P, P, P, P, P, P, P, P, L, I, I, P, P],
     "lcao_triplet_literal": [P, P, P, P, L, P, P, P, L, L, L, L, I, I, I, P, P],
-    "lcao_coeff_mlp_contract": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P],
-    "lcao_coeff_mlp_contract_bf16x3": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, c_size_t, P],
+    "lcao_coeff_mlp_contract": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P],
+    "lcao_coeff_mlp_contract_bf16x3": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, c_size_t, P],
     "lcao_triplet_gemm": [P, P, P, P, P, P, L, L, I, I, P, P],
     "lcao_pair_contract": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],
     "lcao_pair_contract_visit": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],

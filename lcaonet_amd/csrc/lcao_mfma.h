@@ -16,10 +16,18 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define LCAO_ABL 0
 #endif
 #if LCAO_ABL & 1
-#define K2_SILU(x) (x)
+#define K2_ACT(x) (x)
 #else
-#define K2_SILU(x) lcao_silu(x)
+#define K2_ACT(x) lcao_silu_log2e(x)
 #endif
+
+#define LCAO_LOG2E 1.44269504088896340736f
+#define LCAO_INV_LOG2E 0.69314718055994530942f
+
+// g(x') = x' / (1 + 2^(-x')) = SiLU(x) log2 e for x' = x log2 e: v_exp_f32 (negated source), v_add, v_rcp_f32, v_mul
+__device__ __forceinline__ float lcao_silu_log2e(float xs) {
+  return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-xs));
+}
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -42,6 +50,16 @@ __device__ __forceinline__ void stage_weights(float* __restrict__ dst, const flo
   for (int i = threadIdx.x; i < rows * chunks; i += blockDim.x) {
     int rr = i / chunks, cc = i - rr * chunks;
     *(f32x4v*)(dst + rr * (K + 4) + 4 * cc) = *(const f32x4v*)(W + (int64_t)rr * ldw + 4 * cc);
+  }
+}
+
+// stage_weights with every element multiplied by `scale` (constants folded into a layer)
+__device__ __forceinline__ void stage_weights_scaled(float* __restrict__ dst, const float* __restrict__ W, int rows, int K,
+                                                     int ldw, float scale) {
+  const int chunks = K >> 2;
+  for (int i = threadIdx.x; i < rows * chunks; i += blockDim.x) {
+    int rr = i / chunks, cc = i - rr * chunks;
+    *(f32x4v*)(dst + rr * (K + 4) + 4 * cc) = *(const f32x4v*)(W + (int64_t)rr * ldw + 4 * cc) * scale;
   }
 }
 

@@ -160,6 +160,7 @@ extern "C" int lcao_dense(const float* X, int64_t ldx, const float* W, const flo
 template <int C, int V, int NL, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__ cst, const float* __restrict__ rb,
                                                    const int32_t* __restrict__ order,
+                                                   const int32_t* __restrict__ cst_row /* p -> row of cst, or null */,
                                                    const int32_t* __restrict__ l_of_d,
                                                    const float* __restrict__ wmul /* (E,D) or null */,
                                                    const float* __restrict__ W1, const float* __restrict__ W2,
@@ -172,7 +173,11 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
   extern __shared__ float lds[];
   float* w1s = lds;
   float* w2s = lds + V * (C + 4);
-  stage_weights(w1s, W1, V, C, C);
+  // SiLU(h) = h / (1 + 2^(-h log2 e)): W1 is staged pre-multiplied by log2 e, so layer 1 yields h' = h log2 e and the
+  // activation is g(h') = h' rcp(1 + exp2(-h')) = SiLU(h) log2 e — four instructions (v_exp_f32 takes the negation as
+  // a source modifier) instead of five.  The factor cancels through the chain: layer 2 sees W2 g(h') = (W2 SiLU(h))
+  // log2 e = o', the second activation gives SiLU(o) log2 e, and 1 / log2 e is folded into the orbital weight rb[e,d].
+  stage_weights_scaled(w1s, W1, V, C, C, LCAO_LOG2E);
   stage_weights(w2s, W2, V, V, V);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -205,7 +210,11 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
     const bool valid = p < E;
     const int64_t pc = valid ? p : E - 1;
     const int64_t e = order ? order[pc] : pc;
-    const float* xrow = cst + e * (int64_t)D * C + 4 * q;
+    // cst_row: the coefficient rows are GATHERED here (e.g. from the (z_s, z_t) table all edges of a species pair share,
+    // LCAOEmbedding.forward_pair_table) instead of being materialised per edge; every (edge, orbital) row still runs
+    // through both layers below
+    const int64_t ec = cst_row ? (int64_t)cst_row[pc] : e;
+    const float* xrow = cst + ec * (int64_t)D * C + 4 * q;
     const float* rbrow = rb + e * D;
     f32x4v acc[NL][MT];
 #pragma unroll
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[m][j] = K2_SILU(h[m][j]);
+        for (int j = 0; j < 4; ++j) h[m][j] = K2_ACT(h[m][j]);
       f32x4v o[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
 #if !(LCAO_ABL & 8)
       __builtin_amdgcn_s_setprio(0);
 #endif
-      float w = rbrow[d];
+      float w = rbrow[d] * LCAO_INV_LOG2E;
       if (wmul) w *= wmul[e * D + d];
       const int l = l_of_d[d];  // wave-uniform
 #pragma unroll
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ll][m][j] += w * K2_SILU(o[m][j]);
+            for (int j = 0; j < 4; ++j) acc[ll][m][j] += w * K2_ACT(o[m][j]);
         }
       }
     }
@@ -353,8 +362,8 @@ static int coeff_mlp_threads(int n_l) {
 }
 
 template <int C, int V, int NL, int THREADS>
-static int launch_coeff_mlp_t(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
-                              const float* wmul, const float* W1, const float* W2, int64_t E, int D, int accumulate,
+static int launch_coeff_mlp_t(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+                              const int32_t* l_of_d, const float* wmul, const float* W1, const float* W2, int64_t E, int D, int accumulate,
                               float* A, float* Bout, const float* gate, const int32_t* src_p, float* Ag,
                               float* gram, unsigned* counter, hipStream_t st) {
   size_t lds = (size_t(V) * (C + 4) + size_t(V) * (V + 4)) * sizeof(float);
@@ -374,30 +383,30 @@ static int launch_coeff_mlp_t(const float* cst, const float* rb, const int32_t* 
   hipError_t me = hipMemsetAsync(counter, 0, sizeof(unsigned), st);  // re-armed on every call, stream-ordered
   if (me != hipSuccess) return int(me);
   hipLaunchKernelGGL((k_coeff_mlp<C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb, order,
-                     l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, g_clock_probe);
+                     cst_row, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, g_clock_probe);
   return lcao_launch_status();
 }
 
 template <int C, int V, int NL>
-static int launch_coeff_mlp(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
-                            const float* wmul, const float* W1, const float* W2, int64_t E, int D, int accumulate,
+static int launch_coeff_mlp(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+                            const int32_t* l_of_d, const float* wmul, const float* W1, const float* W2, int64_t E, int D, int accumulate,
                             float* A, float* Bout, const float* gate, const int32_t* src_p, float* Ag, float* gram,
                             unsigned* counter, hipStream_t st) {
   if (coeff_mlp_threads(NL) == 512)
-    return launch_coeff_mlp_t<C, V, NL, 512>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate,
+    return launch_coeff_mlp_t<C, V, NL, 512>(cst, rb, order, cst_row, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate,
                                              src_p, Ag, gram, counter, st);
-  return launch_coeff_mlp_t<C, V, NL, 256>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate,
+  return launch_coeff_mlp_t<C, V, NL, 256>(cst, rb, order, cst_row, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate,
                                            src_p, Ag, gram, counter, st);
 }
 
 template <int C, int V>
 static int dispatch_coeff_mlp_nl(int n_l, const float* cst, const float* rb, const int32_t* order,
-                                 const int32_t* l_of_d, const float* wmul, const float* W1, const float* W2,
+                                 const int32_t* cst_row, const int32_t* l_of_d, const float* wmul, const float* W1, const float* W2,
                                  int64_t E, int D, int accumulate, float* A, float* Bout, const float* gate,
                                  const int32_t* src_p, float* Ag, float* gram, unsigned* counter, hipStream_t st) {
 #define CM_NL(NL_) \
   case NL_:        \
-    return launch_coeff_mlp<C, V, NL_>(cst, rb, order, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, st)
+    return launch_coeff_mlp<C, V, NL_>(cst, rb, order, cst_row, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, st)
   switch (n_l) {
     CM_NL(1); CM_NL(2); CM_NL(3); CM_NL(4);
 #undef CM_NL
@@ -411,7 +420,7 @@ extern "C" size_t lcao_lds_bytes_coeff_mlp(int C, int V, int valence) {
 }
 
 extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* order,
-                                       const int32_t* l_of_d, const float* valence_ed, const float* W1,
+                                       const int32_t* cst_row, const int32_t* l_of_d, const float* valence_ed, const float* W1,
                                        const float* W2, const float* gate, const int32_t* src_p, int64_t n_edges,
                                        int n_orb, int C, int V, int n_l, int valence, float* A, float* B, float* Bv,
                                        float* Ag, float* gram, void* workspace, size_t ws_bytes, void* stream) {
@@ -432,12 +441,12 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
 #define CM_CASE(C_, V_)                                                                                            \
   if (C == C_ && V == V_) {                                                                                        \
     if (!valence)                                                                                                  \
-      return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, B,  \
-                                           gate, src_p, Ag, Ag ? gram : nullptr, ctr, st);                         \
-    rc = dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, B,      \
-                                       nullptr, nullptr, nullptr, nullptr, ctr, st);                               \
+      return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, cst_row, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, \
+                                           A, B, gate, src_p, Ag, Ag ? gram : nullptr, ctr, st);                   \
+    rc = dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, cst_row, l_of_d, nullptr, W1, W2, n_edges, n_orb, 0, A, \
+                                       B, nullptr, nullptr, nullptr, nullptr, ctr, st);                            \
     if (rc != LCAO_OK) return rc;                                                                                  \
-    return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, l_of_d, valence_ed, W1, W2 + (size_t)V_ * V_,        \
+    return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, cst_row, l_of_d, valence_ed, W1, W2 + (size_t)V_ * V_, \
                                          n_edges, n_orb, 1, A, Bv, gate, src_p, Ag, Ag ? gram : nullptr, ctr + 1,  \
                                          st);                                                                      \
   }
@@ -1568,9 +1577,10 @@ __device__ __forceinline__ void stage_weights_bf16x2(__bf16* __restrict__ hi, __
 template <int C, int V, int NL, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_coeff_mlp_bf16x3(
     const float* __restrict__ cst, const float* __restrict__ rb, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ l_of_d, const float* __restrict__ W1, const float* __restrict__ W2, int64_t E, int D,
-    float* __restrict__ A, float* __restrict__ Bout, const float* __restrict__ gate, const int32_t* __restrict__ src_p,
-    float* __restrict__ Ag, float* __restrict__ gram, unsigned* __restrict__ tile_counter) {
+    const int32_t* __restrict__ cst_row, const int32_t* __restrict__ l_of_d, const float* __restrict__ W1,
+    const float* __restrict__ W2, int64_t E, int D, float* __restrict__ A, float* __restrict__ Bout,
+    const float* __restrict__ gate, const int32_t* __restrict__ src_p, float* __restrict__ Ag, float* __restrict__ gram,
+    unsigned* __restrict__ tile_counter) {
   static_assert(C % 32 == 0 && V % 32 == 0, "k-steps are 32 wide");
   constexpr int KS1 = C / 32, KS2 = V / 32, MT = V / 16, LD1 = C + 8, LD2 = V + 8, WAVES = THREADS / 64;
   extern __shared__ __bf16 ldsb[];
@@ -1591,7 +1601,8 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_bf16x3(
     const bool valid = p < E;
     const int64_t pc = valid ? p : E - 1;
     const int64_t e = order ? order[pc] : pc;
-    const float* xrow = cst + e * (int64_t)D * C + 8 * q;
+    const int64_t ec = cst_row ? (int64_t)cst_row[pc] : e;   // gathered coefficient rows (see k_coeff_mlp)
+    const float* xrow = cst + ec * (int64_t)D * C + 8 * q;
     const float* rbrow = rb + e * D;
     f32x4v acc[NL][MT];
 #pragma unroll
@@ -1723,8 +1734,8 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_bf16x3(
 }
 
 template <int C, int V, int NL>
-static int launch_coeff_mlp_bf(const float* cst, const float* rb, const int32_t* order, const int32_t* l_of_d,
-                               const float* W1, const float* W2, int64_t E, int D, float* A, float* Bout,
+static int launch_coeff_mlp_bf(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+                               const int32_t* l_of_d, const float* W1, const float* W2, int64_t E, int D, float* A, float* Bout,
                                const float* gate, const int32_t* src_p, float* Ag, float* gram, unsigned* counter,
                                hipStream_t st) {
   constexpr int THREADS = 512;
@@ -1744,12 +1755,12 @@ static int launch_coeff_mlp_bf(const float* cst, const float* rb, const int32_t*
   hipError_t me = hipMemsetAsync(counter, 0, sizeof(unsigned), st);
   if (me != hipSuccess) return int(me);
   hipLaunchKernelGGL((k_coeff_mlp_bf16x3<C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb,
-                     order, l_of_d, W1, W2, E, D, A, Bout, gate, src_p, Ag, gram, counter);
+                     order, cst_row, l_of_d, W1, W2, E, D, A, Bout, gate, src_p, Ag, gram, counter);
   return lcao_launch_status();
 }
 
 extern "C" int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order,
-                                              const int32_t* l_of_d, const float* W1, const float* W2,
+                                              const int32_t* cst_row, const int32_t* l_of_d, const float* W1, const float* W2,
                                               const float* gate, const int32_t* src_p, int64_t n_edges, int n_orb, int C,
                                               int V, int n_l, float* A, float* B, float* Ag, float* gram,
                                               void* workspace, size_t ws_bytes, void* stream) {
@@ -1764,7 +1775,7 @@ extern "C" int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb,
   unsigned* ctr = (unsigned*)workspace;
 #define BF_CASE(C_, V_, NL_)                                                                                       \
   if (C == C_ && V == V_ && n_l == NL_)                                                                            \
-    return launch_coeff_mlp_bf<C_, V_, NL_>(cst, rb, order, l_of_d, W1, W2, n_edges, n_orb, A, B, gate, src_p, Ag, \
+    return launch_coeff_mlp_bf<C_, V_, NL_>(cst, rb, order, cst_row, l_of_d, W1, W2, n_edges, n_orb, A, B, gate, src_p, Ag, \
                                             Ag ? gram : nullptr, ctr, st);
 #define BF_CV(C_, V_) BF_CASE(C_, V_, 1) BF_CASE(C_, V_, 2) BF_CASE(C_, V_, 3) BF_CASE(C_, V_, 4)
   BF_CV(128, 128) BF_CV(64, 64) BF_CV(32, 32)

@@ -103,3 +103,22 @@ extern "C" int lcao_node_tables(const float* x, const float* w_cat, const float*
 #undef NT_CASE
   return LCAO_ERR_UNSUPPORTED;
 }
+
+// row of the (zdim^2, D, C) species-pair table read by edge p: z[src_p[p]] * zdim + z[dst_p[p]]  (cst_row of
+// lcao_coeff_mlp_contract; embed.py:246-249: cst[e] is a function of the two atomic numbers alone)
+__global__ void k_pair_rows(const int64_t* __restrict__ z, const int32_t* __restrict__ src_p,
+                            const int32_t* __restrict__ dst_p, int64_t E, int zdim, int32_t* __restrict__ row) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p < E) row[p] = (int32_t)z[src_p[p]] * zdim + (int32_t)z[dst_p[p]];
+}
+
+extern "C" int lcao_pair_rows(const int64_t* z, const int32_t* src_p, const int32_t* dst_p, int64_t n_edges, int zdim,
+                              int32_t* row, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (zdim <= 0) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(row);
+  hipLaunchKernelGGL(k_pair_rows, dim3(lcao_blocks(n_edges, 256)), dim3(256), 0, (hipStream_t)stream, z, src_p, dst_p,
+                     n_edges, zdim, row);
+  return lcao_launch_status();
+}

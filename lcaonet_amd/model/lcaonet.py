@@ -160,10 +160,14 @@ class LCAOEmbedding(nn.Module):
         t = self.species_tables(dev)
         x = ops.gather_rows(t["x"], z)
         zd = self.max_z + 1
-        zfake = torch.arange(zd, device=dev)
-        src = torch.arange(zd, device=dev, dtype=torch.int32).repeat_interleave(zd)
-        dst = torch.arange(zd, device=dev, dtype=torch.int32).repeat(zd)
-        cst_pair = ops.embed_coeffs(t["FE"], t["U"], t["Vt"], t["scale"], t["shift"], zfake, src, dst)
+        cst_pair = t.get("cst_pair")          # weights only, like the rest of `t`: kept with it
+        if cst_pair is None:
+            zfake = torch.arange(zd, device=dev)
+            src = torch.arange(zd, device=dev, dtype=torch.int32).repeat_interleave(zd)
+            dst = torch.arange(zd, device=dev, dtype=torch.int32).repeat(zd)
+            cst_pair = ops.embed_coeffs(t["FE"], t["U"], t["Vt"], t["scale"], t["shift"], zfake, src, dst)
+            if not torch.cuda.is_current_stream_capturing():
+                t["cst_pair"] = cst_pair
         return x, cst_pair, zd
 
 
@@ -267,8 +271,11 @@ class LCAOInteraction(nn.Module):
                       ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
                       trace: dict | None = None, exact_norm: bool = False, n_own: int | None = None,
                       e_own: int | None = None, pair: tuple | None = None, precision: str = "fp32",
-                      ghost_fn=None) -> Tensor:
+                      ghost_fn=None, cst_row: Tensor | None = None) -> Tensor:
         """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1.
+
+        cst_row (int32, p-space; fused kernels only): cst is then a TABLE of coefficient rows and edge p reads row
+        cst_row[p] — the gather is fused into lcao_coeff_mlp_contract and nothing of size (E, D, C) exists.
 
         n_own / e_own (sharded graphs, lcaonet_amd/shard.py): only the first n_own nodes are centres to update and
         only the first e_own edges of p-space carry messages; the remaining (ghost) nodes and their out-edges feed the
@@ -285,6 +292,8 @@ class LCAOInteraction(nn.Module):
         E, dev = ctx.n_edges, x.device
         if fused is None:
             fused = self._fusable(V if pair is not None else cst.shape[-1])
+        if cst_row is not None and (pair is not None or not fused or (precision == "bf16x3" and self.add_valence)):
+            raise ValueError("forward_fused: cst_row needs the fused per-edge coefficient kernel")
         split = (ghost_fn is not None and fused and pair is None and precision == "fp32" and not exact_norm
                  and not self.add_valence and N > n_own)
         if ghost_fn is not None and not split:
@@ -299,7 +308,7 @@ class LCAOInteraction(nn.Module):
             k2_out = ops.coeff_mlp_buffers(E, V, n_l, dev, True, False)
             k2 = lambda rng: ops.coeff_mlp_contract(
                 cst, rb, ctx.order, l_of_d, None, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(),
-                n_l, False, gate=gate, src_p=ctx.src_p, p_range=rng, out=k2_out)
+                n_l, False, gate=gate, src_p=ctx.src_p, p_range=rng, out=k2_out, cst_row=cst_row)
             k2((0, e_own))                                           # owned centres: gate rows [0, n_own) only
             xg = ghost_fn()
             self._node_level(xg, gate[rows:], None, Pt[rows:])
@@ -327,7 +336,7 @@ class LCAOInteraction(nn.Module):
             # BASELINE config 3: bf16 MFMA on the per-edge coefficient GEMMs, operands split into two bf16 terms
             Ag, gram, B, Bv = ops.coeff_mlp_contract_bf16x3(
                 cst, rb, ctx.order, l_of_d, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(), n_l,
-                gate=None if exact_norm else gate, src_p=ctx.src_p)
+                gate=None if exact_norm else gate, src_p=ctx.src_p, cst_row=cst_row)
             if exact_norm:
                 tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
             else:
@@ -337,12 +346,14 @@ class LCAOInteraction(nn.Module):
                 Ag, gram, B, Bv = ops.coeff_mlp_contract(
                     cst, rb, ctx.order, l_of_d, valence_ed, self.f_coeffs[0].weight.detach(),
                     self.f_coeffs[2].weight.detach(), n_l, self.add_valence,
-                    gate=None if exact_norm else gate, src_p=ctx.src_p)
+                    gate=None if exact_norm else gate, src_p=ctx.src_p, cst_row=cst_row)
             if exact_norm:   # per-triplet V-long norm (validation of the Gram-matrix form)
                 tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
             else:
                 tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
         else:
+            if cst_row is not None:
+                raise ValueError("forward_fused: cst_row needs the fused coefficient kernel (widths in ops.FUSED_COEFF_SHAPES)")
             cstf = run_mlp(self.f_coeffs, cst)
             A, B, Bv = ops.coeff_contract(cstf, rb, ctx.order, l_of_d, valence_ed, V, n_l, self.add_valence)
             tbw = ops.triplet_sum(A, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
@@ -536,6 +547,11 @@ class LCAONet(BaseMPNN):
         """graph: PyG-Batch-like object with z, pos, edge_index [centre, neighbour], edge_shift, lattice and
         optionally batch.  Returns (B, out_size) or ((B, out_size), (N, 3)) exactly like the reference.
 
+        cst_mode: "edge" (default) — the general per-edge coefficient MLP: every (edge, orbital) row runs through both
+        f_coeffs layers; in eval mode with the fused kernel the rows are gathered from the species-pair table inside the
+        kernel, so the (E, D, C) tensor is never materialised.  "edge_tensor": the same with cst materialised per edge as
+        the reference holds it.  "pair": f_coeffs evaluated on the pair table itself (fewer flops).
+
         precision: "fp32" (default; exact fp32 MFMA) or "bf16x3" (BASELINE config 3: the per-edge coefficient GEMMs on
         bf16 MFMA with two-term operand splitting; ~1e-5 from fp32 where plain bf16 would be 4e-3).
 
@@ -574,6 +590,14 @@ class LCAONet(BaseMPNN):
         ValenceMask.forward(z, idx_t))."""
         return self.valence_mask.valence[:zdim].to(torch.float32).repeat(zdim, 1).contiguous()
 
+    def _gathers_cst(self, fused: bool | None, precision: str) -> bool:
+        """Eval mode with the fused coefficient kernel on every layer: the coefficient rows are gathered in-kernel."""
+        if self.training or fused is False:
+            return False
+        if precision == "bf16x3" and (self.add_valence or self.emb_size_coeff != self.emb_size_conv):
+            return False
+        return all(layer._fusable(self.emb_size_coeff) for layer in self.int_layers)
+
     @torch.no_grad()
     def _forward_inference(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
                            trace: dict | None = None, exact_norm: bool = False, cst_mode: str = "edge",
@@ -600,7 +624,7 @@ class LCAONet(BaseMPNN):
             graph = self.calc_3body_angles(self.get_triplets(graph))
 
         rb = self.rbf(dist)
-        pair = None
+        pair = cst_row = None
         if cst_mode == "pair":
             # cst_mode="pair": species-pair table instead of the per-edge (E, D, C) tensor.  Same
             # outputs; valid when cst comes from this model's own embedding in eval mode.
@@ -608,20 +632,28 @@ class LCAONet(BaseMPNN):
                 raise NotImplementedError("cst_mode='pair' needs eval mode (train mode: differentiable=True)")
             x, cst, zdim = self.emb_layer.forward_pair_table(z)
             pair = (z, zdim, self.pair_valence_mask(zdim) if self.add_valence else None)
-        elif cst_mode != "edge":
-            raise ValueError(f"cst_mode={cst_mode!r}: expected 'edge' or 'pair'")
+        elif cst_mode not in ("edge", "edge_tensor"):
+            raise ValueError(f"cst_mode={cst_mode!r}: expected 'edge', 'edge_tensor' or 'pair'")
         elif self.training:
             x, cst = self.emb_layer(z, idx_s, idx_t)  # BatchNorm batch statistics: module path
+        elif cst_mode == "edge" and self._gathers_cst(fused, precision):
+            # every (edge, orbital) row still goes through both f_coeffs layers, but the rows are read from the
+            # species-pair table inside the kernel (cst[e] is a function of (z_s, z_t), embed.py:246-249): the (E, D, C)
+            # tensor — 4.6 GB at the 1 M-edge config — is never written or re-read
+            x, cst, zdim = self.emb_layer.forward_pair_table(z)
+            cst_row = ops.pair_rows(z, ctx.src_p, ctx.dst_p, zdim)
         else:
             x, cst = self.emb_layer.forward_species(z, ctx)
         valence_ed = self.valence_mask.per_edge(z, idx_t) if self.add_valence else None
 
         if trace is not None:
-            trace.update(rb=rb, x0=x, cst=cst, order=ctx.order)  # cst: pair table in cst_mode="pair"
+            # cst: the per-edge tensor the reference holds (materialised for the trace only); pair table in cst_mode="pair"
+            cst_tr = cst if cst_row is None else self.emb_layer.forward_species(z, ctx)[1]
+            trace.update(rb=rb, x0=x, cst=cst_tr, order=ctx.order)
         for i, inte in enumerate(self.int_layers):
             tr = {} if trace is not None else None
             x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr, exact_norm,
-                                   pair=pair, precision=precision)
+                                   pair=pair, precision=precision, cst_row=cst_row)
             if trace is not None:
                 trace[f"x{i + 1}"] = x
                 trace[f"three_body_w{i + 1}"] = tr["three_body_w"]

@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 from torch import Tensor
 
+from .. import ops
 from ..data.keys import GraphKeys
 from ..nn.base import run_mlp
 from ..nn.scatter import scatter
@@ -29,7 +30,13 @@ class ShardedForward:
         graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
         self.uvec = graph[GraphKeys.Edge_vec_st]
         self.rb = model.rbf(graph[GraphKeys.Edge_dist])
-        self.x0, self.cst = model.emb_layer.forward_species(z, self.ctx)      # static inputs: every local row is known
+        # static inputs: every local row (ghosts included) is known without an exchange
+        self.cst_row = None
+        if model._gathers_cst(fused, "fp32"):
+            self.x0, self.cst, zdim = model.emb_layer.forward_pair_table(z)
+            self.cst_row = ops.pair_rows(z, self.ctx.src_p, self.ctx.dst_p, zdim)
+        else:
+            self.x0, self.cst = model.emb_layer.forward_species(z, self.ctx)
         idx_t = graph[GraphKeys.Edge_idx][1]
         self.valence_ed = model.valence_mask.per_edge(z, idx_t) if model.add_valence else None
         self.x_own = None
@@ -45,7 +52,7 @@ class ShardedForward:
             x, gf = self.x_own, ghost_fn
         self.x_own = m.int_layers[i].forward_fused(x, self.cst, self.valence_ed, self.rb, self.uvec, self.ctx,
                                                    m.shbf.l_of_d, m.n_l, self.fused, None, False, p.n_own, p.e_own,
-                                                   ghost_fn=gf)
+                                                   ghost_fn=gf, cst_row=self.cst_row)
         return self.x_own
 
     @torch.no_grad()

@@ -263,7 +263,7 @@ def coeff_contract(cstf, rb, order, l_of_d, mask, V, n_l, valence):
     return A, B, Bv
 
 
-def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, src_p=None):
+def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, src_p=None, cst_row=None):
     """bf16-MFMA ("bf16x3" split) variant of coeff_mlp_contract; same outputs (no valence)."""
     cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
     E, D = rb.shape
@@ -277,18 +277,20 @@ def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, sr
     if gated:
         gate = _f32(gate, "gate")
     ws = torch.empty(2, device=dev, dtype=torch.int32)
-    _call("lcao_coeff_mlp_contract_bf16x3", _p(cst), _p(rb), _p(order), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
+    _call("lcao_coeff_mlp_contract_bf16x3", _p(cst), _p(rb), _p(order), _p(cst_row), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
           D, C, V, n_l, _p(A), _p(B), _p(Ag), _p(gram), _p(ws), 8, _stream())
     return (Ag if gated else A), gram, B, None
 
 
 def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence, gate=None, src_p=None, p_range=None,
-                       out=None):
+                       out=None, cst_row=None):
     """Fused f_coeffs + radial contraction.  With `gate` (N,V) and `src_p`: returns (Ag, gram, B, Bv) for
     triplet_gemm; without: (A, None, B, Bv) for the exact-norm triplet_sum.
     p_range = (p0, p1): only the edges [p0, p1) of p-space, written into rows [p0, p1) of `out` = the tuple a full call
     returned or `coeff_mlp_buffers(...)` allocated (sharded graphs: the owned-centre edges run while the halo exchange
-    is in flight, the ghost-centred ones after it)."""
+    is in flight, the ghost-centred ones after it).
+    cst_row (int32, p-space): edge p reads row cst_row[p] of `cst` — the gather of the coefficient rows fused into the
+    kernel (cst = a table shared by many edges, e.g. the species-pair table; nothing of size (E, D, C) exists)."""
     cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
     E, D = rb.shape
     V, C = W1.shape
@@ -306,10 +308,19 @@ def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence,
         if order is None and p0 != 0:
             raise ValueError("coeff_mlp_contract: a p-range needs the order array")
         ws = torch.empty(2, device=dev, dtype=torch.int32)  # tile-queue counters (the library zeroes them on the stream)
-        _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(sl(order)), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2),
+        _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(sl(order)), _p(sl(cst_row)), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2),
               _p(gate), _p(sl(src_p)), p1 - p0, D, C, V, n_l, int(valence), _p(sl(A)), _p(sl(B)), _p(sl(Bv)), _p(sl(Ag)),
               _p(sl(gram)), _p(ws), 8, _stream())
     return (Ag if gated else A), gram, B, Bv
+
+
+def pair_rows(z: Tensor, src_p: Tensor, dst_p: Tensor, zdim: int) -> Tensor:
+    """int32 (E): row of the (zdim^2, D, C) species-pair table each p-space edge reads (cst_row of coeff_mlp_contract)."""
+    z = _i64(z, "z")
+    E = src_p.numel()
+    row = torch.empty(E, device=z.device, dtype=torch.int32)
+    _call("lcao_pair_rows", _p(z), _p(_i32(src_p)), _p(_i32(dst_p)), E, zdim, _p(row), _stream())
+    return row
 
 
 def coeff_mlp_buffers(E, V, n_l, dev, gated: bool, valence: bool):

@@ -435,7 +435,7 @@ def test_sharded_autograd_forces_match_unsharded(dev, world, case):
     assert counts == {"exchange": L - 1, "reduce": 1, "reverse": osz * L}     # (L-1) x dE/dx + 1 x dE/dpos per output
     seen = torch.zeros(g["z"].numel(), dtype=torch.bool, device=dev)
     for p, (out, f) in zip(plans, results):
-        assert relerr(out, want_out) <= 2e-6
+        assert relerr(out, want_out) <= 5e-6     # per-rank partial sums added in another order than the unsharded sum
         assert f.shape[0] == p.n_own
         assert relerr(f, want_f[p.owned_global]) <= 2e-5, (p.rank, relerr(f, want_f[p.owned_global]))
         seen[p.owned_global] = True
@@ -444,7 +444,7 @@ def test_sharded_autograd_forces_match_unsharded(dev, world, case):
     solo = shard.make_plans(g, 1)[0]
     out1, f1 = m.forward_sharded(solo, exchange_fn=lambda x: x[:0], reduce_fn=lambda t: t,
                                  reverse_fn=lambda gq: gq.new_zeros(solo.n_own, gq.shape[1]))
-    assert relerr(out1, want_out) <= 2e-6 and relerr(f1, want_f) <= 2e-5
+    assert relerr(out1, want_out) <= 5e-6 and relerr(f1, want_f) <= 2e-5
 
 
 @pytest.mark.parametrize("width,heads,valence", [(128, 64, False), (64, 64, False), (32, 16, False), (48, 16, False),
