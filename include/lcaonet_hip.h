@@ -291,6 +291,22 @@ int lcao_pair_table_grad(const float* g_A, const float* rb, const int32_t* order
 int lcao_geometry_bwd(const float* dist, const float* uvec, const float* g_rb, const float* g_u, int64_t n_edges, int n_orb,
                       const float* orb_table, int rbf_kind, int cutoff_kind, float rc, float* g_vec, void* stream);
 
+/* ---- exact double backward of autograd-force training (lcaonet.py:310-317, create_graph=True) ---------------------
+ * The three-body sum of lcaonet.py:173-189 with the per-triplet scalar weights w (T, n_l) as an INPUT tensor:
+ *   spmm  : out[p,:]   = sum_{q in In(src(p)), l} w[t(p,q),l] * A[q,l,:]           (E, V)
+ *   spmm_t: out[q,l,:] = sum_{p in Out(dst(q))}   w[t(p,q),l] * G[p,:]             (E, n_l, V)
+ *   sddmm : out[t,l]   = G[p,:] . A[q,l,:]                                          (T, n_l)
+ * a bilinear family closed under differentiation (each op's two derivatives are the other two), so autograd can
+ * differentiate the backward pass again.  Triplet slot t(p,q) = tbase[s] + rank_out(p) * m_in(s) + rank_in(q) with
+ * s = src(p) = dst(q); in_rank[q] = rank of q in its node's in-list.  Any V <= 512; deterministic. */
+int lcao_trip_spmm(const float* w, const float* A, const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos,
+                   const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int V, int n_l, float* out, void* stream);
+int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* dst_p, const int32_t* in_rank, const int32_t* in_ptr,
+                     const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int V, int n_l,
+                     float* out, void* stream);
+int lcao_trip_sddmm(const float* G, const float* A, const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos,
+                    const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int V, int n_l, float* out, void* stream);
+
 size_t lcao_lds_bytes_coeff_mlp(int C, int V, int valence);
 
 /* Diagnostics only (tools/clock_probe.py): buffer of 2 x uint64 per wave of lcao_coeff_mlp_contract receiving

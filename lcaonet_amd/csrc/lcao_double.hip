@@ -1,0 +1,199 @@
+// lcao_double.hip — the three-body term as a sparse bilinear family that is closed under differentiation, for the
+// EXACT double backward of autograd-force training (lcaonet/model/lcaonet.py:310-317, create_graph=True).
+//
+// lcaonet.py:173-189 per centre node s:   tbw[p, :] = sum_{q in In(s)} sum_l  w[t(p,q), l] * Ag[q, l, :]
+// with one scalar weight vector w[t, :] (n_l floats) per triplet t = (out-edge p, in-edge q).  In the inference kernels
+// w = Y_l(u_p . u_q) / |.| is recomputed in registers; here it is an INPUT (a T-sized tensor of scalars built by
+// ordinary differentiable tensor ops, model/double.py), which makes the op bilinear in (w, Ag) and gives the family
+//     spmm  (w, A) -> out[p,:]   = sum_{q,l} w[t,l] A[q,l,:]
+//     spmm_t(w, G) -> out[q,l,:] = sum_p     w[t,l] G[p,:]
+//     sddmm (G, A) -> out[t,l]   = G[p,:] . A[q,l,:]
+// whose derivatives are each other:  d spmm/dw = sddmm(g, A), d spmm/dA = spmm_t(w, g);  d spmm_t/dw = sddmm(G, g),
+// d spmm_t/dG = spmm(w, g);  d sddmm/dG = spmm(g, A), d sddmm/dA = spmm_t(g, G).  So autograd can differentiate the
+// backward pass again without any further kernel.
+//
+// Triplet layout ("dense per-node blocks"): node s owns the block tbase[s] + i * m_in(s) + j, i = rank of the out-edge
+// p = out_ptr[s] + i, j = rank of the in-edge q = in_pos[in_ptr[s] + j].  The pair q == p (dropped by lcaonet.py:470) has
+// a slot too; the caller gives it w = 0.  Any V <= 512; one wave per edge, lanes over channels; no atomics.
+#include "lcao_common.h"
+
+template <int R>
+__global__ void k_trip_spmm(const float* __restrict__ w, const float* __restrict__ A, const int32_t* __restrict__ src_p,
+                            const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_pos,
+                            const int32_t* __restrict__ out_ptr, const int64_t* __restrict__ tbase, int64_t n_edges,
+                            int V, int NL, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; p < n_edges; p += nwave) {
+    const int s = src_p[p];
+    const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
+    const int64_t t0 = tbase[s] + (int64_t)(p - out_ptr[s]) * m_in;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int j = 0; j < m_in; ++j) {
+      const int64_t q = in_pos[j0 + j];
+      for (int l = 0; l < NL; ++l) {
+        const float wv = w[(t0 + j) * NL + l];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          if (ch < V) acc[r] += wv * A[(q * NL + l) * V + ch];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ch = lane + 64 * r;
+      if (ch < V) out[p * V + ch] = acc[r];
+    }
+  }
+}
+
+// one wave per in-edge q (of node s = dst_p[q], rank j = in_rank[q]); output row (q, l, :) for every l
+template <int R, int NLMAX>
+__global__ void k_trip_spmm_t(const float* __restrict__ w, const float* __restrict__ G, const int32_t* __restrict__ dst_p,
+                              const int32_t* __restrict__ in_rank, const int32_t* __restrict__ in_ptr,
+                              const int32_t* __restrict__ out_ptr, const int64_t* __restrict__ tbase, int64_t n_edges,
+                              int n_centres, int V, int NL, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; q < n_edges; q += nwave) {
+    const int s = dst_p[q];
+    float acc[NLMAX][R];
+#pragma unroll
+    for (int l = 0; l < NLMAX; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[l][r] = 0.f;
+    if (s < n_centres) {   // in-edges of nodes that are not centres here (ghosts of a sharded graph) get zero rows
+      const int m_in = in_ptr[s + 1] - in_ptr[s];
+      const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
+      const int64_t tq = tbase[s] + in_rank[q];
+      for (int i = 0; i < m_out; ++i) {
+        const int64_t t = tq + (int64_t)i * m_in;
+        float g[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          g[r] = ch < V ? G[(int64_t)(p0 + i) * V + ch] : 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < NLMAX; ++l) {
+          if (l < NL) {
+            const float wv = w[t * NL + l];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[l][r] += wv * g[r];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < NLMAX; ++l)
+      if (l < NL) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          if (ch < V) out[(q * NL + l) * V + ch] = acc[l][r];
+        }
+      }
+  }
+}
+
+template <int R>
+__global__ void k_trip_sddmm(const float* __restrict__ G, const float* __restrict__ A, const int32_t* __restrict__ src_p,
+                             const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_pos,
+                             const int32_t* __restrict__ out_ptr, const int64_t* __restrict__ tbase, int64_t n_edges,
+                             int V, int NL, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t p = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; p < n_edges; p += nwave) {
+    const int s = src_p[p];
+    const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
+    const int64_t t0 = tbase[s] + (int64_t)(p - out_ptr[s]) * m_in;
+    float g[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ch = lane + 64 * r;
+      g[r] = ch < V ? G[p * V + ch] : 0.f;
+    }
+    for (int j = 0; j < m_in; ++j) {
+      const int64_t q = in_pos[j0 + j];
+      for (int l = 0; l < NL; ++l) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          if (ch < V) d += g[r] * A[(q * NL + l) * V + ch];
+        }
+        d = lcao_wave_sum(d);
+        if (lane == 0) out[(t0 + j) * NL + l] = d;
+      }
+    }
+  }
+}
+
+static int check_trip(int64_t n_edges, int V, int n_l) {
+  if (n_edges < 0 || n_edges >= (int64_t(1) << 31)) return LCAO_ERR_INVALID;
+  if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  return LCAO_OK;
+}
+
+#define TRIP_DISPATCH(KERNEL, ...)                                                        \
+  do {                                                                                    \
+    const int R_ = (V + 63) / 64;                                                         \
+    dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);                                \
+    if (R_ == 1) hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, st, __VA_ARGS__);        \
+    else if (R_ == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, st, __VA_ARGS__);   \
+    else if (R_ <= 4) hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, st, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, st, __VA_ARGS__);                \
+  } while (0)
+
+extern "C" int lcao_trip_spmm(const float* w, const float* A, const int32_t* src_p, const int32_t* in_ptr,
+                              const int32_t* in_pos, const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int V,
+                              int n_l, float* out, void* stream) {
+  int rc = check_trip(n_edges, V, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(w); LCAO_CHECK_PTR(A); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(in_ptr); LCAO_CHECK_PTR(in_pos);
+  LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(out);
+  hipStream_t st = (hipStream_t)stream;
+  TRIP_DISPATCH(k_trip_spmm, w, A, src_p, in_ptr, in_pos, out_ptr, tbase, n_edges, V, n_l, out);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_trip_sddmm(const float* G, const float* A, const int32_t* src_p, const int32_t* in_ptr,
+                               const int32_t* in_pos, const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int V,
+                               int n_l, float* out, void* stream) {
+  int rc = check_trip(n_edges, V, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(A); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(in_ptr); LCAO_CHECK_PTR(in_pos);
+  LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(out);
+  hipStream_t st = (hipStream_t)stream;
+  TRIP_DISPATCH(k_trip_sddmm, G, A, src_p, in_ptr, in_pos, out_ptr, tbase, n_edges, V, n_l, out);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* dst_p, const int32_t* in_rank,
+                                const int32_t* in_ptr, const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges,
+                                int64_t n_centres, int V, int n_l, float* out, void* stream) {
+  int rc = check_trip(n_edges, V, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_centres < 0 || n_centres >= (int64_t(1) << 31)) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(w); LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(in_rank); LCAO_CHECK_PTR(in_ptr);
+  LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(out);
+  hipStream_t st = (hipStream_t)stream;
+  const int R_ = (V + 63) / 64;
+  dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
+#define TT(RR) \
+  hipLaunchKernelGGL((k_trip_spmm_t<RR, 4>), grid, block, 0, st, w, G, dst_p, in_rank, in_ptr, out_ptr, tbase, n_edges, \
+                     (int)n_centres, V, n_l, out)
+  if (R_ == 1) TT(1);
+  else if (R_ == 2) TT(2);
+  else if (R_ <= 4) TT(4);
+  else TT(8);
+#undef TT
+  return lcao_launch_status();
+}

@@ -1,0 +1,440 @@
+"""EXACT autograd forces with a graph: F = -dE/dpos that can itself be differentiated (training on forces, reference
+lcaonet/model/lcaonet.py:310-317 `torch.autograd.grad(..., create_graph=True)`, tests/model/test_lcaonet.py:219-243).
+
+The inference sweep (model/forces.py) and the training sweep (model/train.py) are hand-written first-order passes: fast,
+but autograd cannot see inside them.  Here the energy is assembled from primitives that are each TWICE differentiable:
+
+  * linear / bilinear HIP ops wrapped as autograd Functions whose backward calls the same family again, so the second
+    derivative needs no further kernel:
+        dense     y = x W^T + b            <->  wgrad  dW = g^T x                      (lcao_dense, lcao_wgrad)
+        gather    rows = table[idx]        <->  scatter  out[i] = sum_{idx[r]=i} rows[r]   (sorted segments, no atomics)
+        orbital contraction  A[p,l,:] = sum_{d in l} rb[p,d] T[pair(p),d,:]  with its two partial derivatives
+                                                    (lcao_pair_contract, lcao_pair_contract_bwd, lcao_pair_table_grad)
+        three-body sum  tbw[p,:] = sum_{q,l} w[t,l] Ag[q,l,:]  with spmm_t / sddmm       (csrc/lcao_double.hip)
+  * everything non-linear is an elementwise (or per-row) tensor op under ordinary autograd: SiLU, sigmoid, F.normalize,
+    the radial basis R_nl(dist) on the (E, D) table, and the per-triplet scalars Y_l(cos) / |.| on (T, n_l).
+
+So `torch.autograd.grad(E, pos, create_graph=True)` is exact (no step size), and a loss on the forces back-propagates to
+every parameter through the second derivative.  Cost: this path materialises T-sized SCALAR tensors (never (T, V)) and
+keeps autograd's intermediates; it is the training-on-forces mode, not the inference path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from torch.autograd import Function
+
+from .. import ops
+from ..data.keys import GraphKeys
+
+Y0 = 0.28209479177387814
+Y1 = 0.48860251190292
+Y2A, Y2B = 0.94617469575756, 0.31539156525252
+Y3 = 0.373176332590115
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dense <-> wgrad
+# ---------------------------------------------------------------------------------------------------------------------
+class _DenseFn(Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        return ops.dense(x, W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = g.contiguous()
+        gx = dense(g, W.t()) if ctx.needs_input_grad[0] else None
+        gW = wgrad(g, x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return gx, gW, gb
+
+
+class _WgradFn(Function):
+    """dW (M, K) = g^T x for g (E, M), x (E, K)."""
+
+    @staticmethod
+    def forward(ctx, g, x):
+        ctx.save_for_backward(g, x)
+        return ops.wgrad(g, x)
+
+    @staticmethod
+    def backward(ctx, c):
+        g, x = ctx.saved_tensors
+        c = c.contiguous()
+        gg = dense(x, c) if ctx.needs_input_grad[0] else None             # x c^T
+        gx = dense(g, c.t()) if ctx.needs_input_grad[1] else None         # g c
+        return gg, gx
+
+
+def dense(x: Tensor, W: Tensor, b: Tensor | None = None) -> Tensor:
+    """x W^T + b on the last dim of x; differentiable to any order in x, W, b."""
+    lead = x.shape[:-1]
+    y = _DenseFn.apply(x.reshape(-1, x.shape[-1]), W, b)
+    return y.reshape(*lead, W.shape[0])
+
+
+def wgrad(g: Tensor, x: Tensor) -> Tensor:
+    return _WgradFn.apply(g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gather <-> scatter (deterministic: rows grouped by a stable sort of the index)
+# ---------------------------------------------------------------------------------------------------------------------
+class IndexPlan:
+    """An index vector (n_out rows picking from n_rows table rows) with the sorted-segment structure of its adjoint."""
+
+    def __init__(self, idx: Tensor, n_rows: int, is_sorted: bool = False):
+        self.idx = idx.to(torch.int64).contiguous()
+        self.n_rows = n_rows
+        if is_sorted:
+            perm = torch.arange(idx.numel(), device=idx.device)
+            srt = self.idx
+        else:
+            perm = torch.argsort(self.idx, stable=True)
+            srt = self.idx[perm]
+        self.perm = perm.to(torch.int32)
+        bounds = torch.arange(n_rows + 1, device=idx.device, dtype=torch.int64)
+        self.ptr = torch.searchsorted(srt, bounds).to(torch.int32)
+
+
+class _GatherFn(Function):
+    @staticmethod
+    def forward(ctx, table, plan: IndexPlan):
+        ctx.plan = plan
+        return ops.gather_rows(table, plan.idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScatterFn.apply(g.contiguous(), ctx.plan), None
+
+
+class _ScatterFn(Function):
+    @staticmethod
+    def forward(ctx, rows, plan: IndexPlan):
+        ctx.plan = plan
+        return ops.segment_sum_gather(rows, plan.perm, plan.ptr)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _GatherFn.apply(g.contiguous(), ctx.plan), None
+
+
+def gather(table: Tensor, plan: IndexPlan) -> Tensor:
+    """table[plan.idx] for a (n_rows, ...) table."""
+    tail = table.shape[1:]
+    out = _GatherFn.apply(table.reshape(table.shape[0], -1) if table.dim() != 2 else table, plan)
+    return out.reshape((plan.idx.numel(),) + tuple(tail))
+
+
+def scatter_sum(rows: Tensor, plan: IndexPlan) -> Tensor:
+    """out[i] = sum of rows[r] over r with plan.idx[r] == i, (plan.n_rows, ...)."""
+    tail = rows.shape[1:]
+    out = _ScatterFn.apply(rows.reshape(rows.shape[0], -1) if rows.dim() != 2 else rows, plan)
+    return out.reshape((plan.n_rows,) + tuple(tail))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# orbital contraction with the species-pair table (bilinear in rb and T)
+# ---------------------------------------------------------------------------------------------------------------------
+class _Geo:
+    """Static index structures of one graph, everything in p-space (edges sorted by centre)."""
+
+    def __init__(self, model, graph):
+        from .lcaonet import EdgeContext
+
+        z = graph[GraphKeys.Z]
+        dev = z.device
+        self.z, self.N = z, z.numel()
+        ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], self.N)
+        self.ctx, self.E = ctx, ctx.n_edges
+        self.l_of_d, self.n_l = model.shbf.l_of_d, model.n_l
+        self.zdim = model.emb_layer.max_z + 1
+        order = ctx.order.long()
+        self.src, self.dst = IndexPlan(ctx.src_p, self.N, is_sorted=True), IndexPlan(ctx.dst_p, self.N)
+        self.zplan = IndexPlan(z, self.zdim)
+        batch = graph.get(GraphKeys.Batch_idx)
+        shift = graph[GraphKeys.Edge_shift][order].float()
+        lat = graph[GraphKeys.Lattice].float().reshape(-1, 3, 3)
+        b_src = batch[ctx.src_p.long()] if batch is not None else torch.zeros(self.E, dtype=torch.long, device=dev)
+        self.cell_shift = torch.einsum("ni,nij->nj", shift, lat[b_src]).contiguous()      # constant part of edge vectors
+        # pair rows and the pair-sorted chunk lists of lcao_pair_table_grad
+        self.ones_gate = torch.ones(self.N, model.emb_size_conv, device=dev)
+        pair_p = z[ctx.src_p.long()] * self.zdim + z[ctx.dst_p.long()]
+        self._pair_lists(pair_p)
+        # triplet slots: node s owns tbase[s] + i * m_in(s) + j
+        m_in = (ctx.in_ptr[1:] - ctx.in_ptr[:-1]).long()
+        m_out = (ctx.out_ptr[1:] - ctx.out_ptr[:-1]).long()
+        prod = m_in * m_out
+        self.tbase = (torch.cumsum(prod, 0) - prod).contiguous()
+        T = int(prod.sum().item())                                   # host sync: this mode sizes T-long scalar tensors
+        self.T = T
+        node = torch.repeat_interleave(torch.arange(self.N, device=dev), prod, output_size=T)
+        local = torch.arange(T, device=dev) - self.tbase[node]
+        mi = m_in[node].clamp(min=1)
+        tri_p = ctx.out_ptr[:-1].long()[node] + torch.div(local, mi, rounding_mode="floor")
+        tri_q = ctx.in_pos.long()[ctx.in_ptr[:-1].long()[node] + local % mi]
+        self.tp, self.tq = IndexPlan(tri_p, self.E, is_sorted=True), IndexPlan(tri_q, self.E)
+        self.tmask = (tri_p != tri_q).float().unsqueeze(1)           # lcaonet.py:470 drops the pair q == p
+        in_rank = torch.empty(self.E, dtype=torch.int32, device=dev)
+        k = torch.arange(self.E, device=dev)
+        in_rank[ctx.in_pos.long()] = (k - ctx.in_ptr[:-1].long()[ctx.dst_p.long()[ctx.in_pos.long()]]).to(torch.int32)
+        self.in_rank = in_rank
+
+    def _pair_lists(self, pair_p: Tensor, chunk: int = 64):
+        zz = self.zdim * self.zdim
+        dev = pair_p.device
+        perm = torch.argsort(pair_p, stable=True)
+        bounds = torch.arange(zz + 1, device=dev, dtype=pair_p.dtype)
+        ptr = torch.searchsorted(pair_p[perm], bounds)
+        n_chunks = (ptr[1:] - ptr[:-1] + chunk - 1) // chunk
+        cptr = torch.zeros(zz + 1, dtype=torch.long, device=dev)
+        cptr[1:] = torch.cumsum(n_chunks, 0)
+        total = (pair_p.numel() + chunk - 1) // chunk + zz
+        cid = torch.arange(total + 1, device=dev)
+        seg = torch.searchsorted(cptr[1:], cid, right=True).clamp(max=zz - 1)
+        lo = torch.minimum(ptr[seg] + (cid - cptr[seg]) * chunk, ptr[seg + 1])
+        lo = torch.where(cid < cptr[-1], lo, ptr[-1].expand_as(lo))
+        self.perm_pair = perm.to(torch.int32)
+        self.chunk_ptr = torch.cat([lo[:total], ptr[-1:]]).to(torch.int32)
+        self.pair_cptr = torch.clamp(cptr, max=total).to(torch.int32)
+
+
+def _c1(geo: _Geo, rb, T):      # A (E, n_l, V)
+    c = geo.ctx
+    return ops.pair_contract(T, rb, None, geo.l_of_d, geo.z, c.src_p, c.dst_p, geo.ones_gate[:, : T.shape[-1]].contiguous(),
+                             geo.n_l, geo.zdim)[0]
+
+
+def _c2(geo: _Geo, gA, T):      # d/drb: (E, D)
+    c = geo.ctx
+    E, D = geo.E, T.shape[1]
+    g_rb = torch.zeros(E, D, device=gA.device)
+    zero_b = torch.zeros(E, T.shape[-1], device=gA.device)
+    zero_g = torch.zeros(E, 10, device=gA.device)
+    rb_any = torch.zeros(E, D, device=gA.device)
+    ops.pair_contract_bwd(T, rb_any, None, geo.l_of_d, geo.z, c.src_p, c.dst_p, geo.ones_gate[:, : T.shape[-1]].contiguous(),
+                          gA, zero_b, zero_g, E, geo.n_l, geo.zdim, g_rb)
+    return g_rb
+
+
+def _c3(geo: _Geo, gA, rb, V):  # d/dT: (zdim^2, D, V)
+    D = rb.shape[1]
+    partial = ops.pair_table_grad(gA, rb, None, geo.l_of_d, geo.perm_pair, geo.chunk_ptr)
+    return ops.segment_sum(partial.reshape(partial.shape[0], D * V), geo.pair_cptr).reshape(-1, D, V)
+
+
+class _ContractFn(Function):
+    @staticmethod
+    def forward(ctx, rb, T, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(rb, T)
+        return _c1(geo, rb.contiguous(), T.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        rb, T = ctx.saved_tensors
+        g = g.contiguous()
+        return (_ContractDrbFn.apply(g, T, ctx.geo) if ctx.needs_input_grad[0] else None,
+                _ContractDtFn.apply(g, rb, ctx.geo) if ctx.needs_input_grad[1] else None, None)
+
+
+class _ContractDrbFn(Function):
+    """out[p,d] = gA[p,l(d),:] . T[pair(p),d,:]"""
+
+    @staticmethod
+    def forward(ctx, gA, T, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(gA, T)
+        return _c2(geo, gA.contiguous(), T.contiguous())
+
+    @staticmethod
+    def backward(ctx, c):
+        gA, T = ctx.saved_tensors
+        c = c.contiguous()
+        return (_ContractFn.apply(c, T, ctx.geo) if ctx.needs_input_grad[0] else None,
+                _ContractDtFn.apply(gA, c, ctx.geo) if ctx.needs_input_grad[1] else None, None)
+
+
+class _ContractDtFn(Function):
+    """out[r,d,:] = sum_{p: pair(p)=r} rb[p,d] gA[p,l(d),:]"""
+
+    @staticmethod
+    def forward(ctx, gA, rb, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(gA, rb)
+        return _c3(geo, gA.contiguous(), rb.contiguous(), gA.shape[-1])
+
+    @staticmethod
+    def backward(ctx, c):
+        gA, rb = ctx.saved_tensors
+        c = c.contiguous()
+        return (_ContractFn.apply(rb, c, ctx.geo) if ctx.needs_input_grad[0] else None,
+                _ContractDrbFn.apply(gA, c, ctx.geo) if ctx.needs_input_grad[1] else None, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# three-body sum with explicit per-triplet weights (csrc/lcao_double.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+class _SpmmFn(Function):
+    @staticmethod
+    def forward(ctx, w, A, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(w, A)
+        return ops.trip_spmm(w.contiguous(), A.contiguous(), geo)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, A = ctx.saved_tensors
+        g = g.contiguous()
+        return (_SddmmFn.apply(g, A, ctx.geo) if ctx.needs_input_grad[0] else None,
+                _SpmmTFn.apply(w, g, ctx.geo) if ctx.needs_input_grad[1] else None, None)
+
+
+class _SpmmTFn(Function):
+    @staticmethod
+    def forward(ctx, w, G, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(w, G)
+        return ops.trip_spmm_t(w.contiguous(), G.contiguous(), geo)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, G = ctx.saved_tensors
+        g = g.contiguous()
+        return (_SddmmFn.apply(G, g, ctx.geo) if ctx.needs_input_grad[0] else None,
+                _SpmmFn.apply(w, g, ctx.geo) if ctx.needs_input_grad[1] else None, None)
+
+
+class _SddmmFn(Function):
+    @staticmethod
+    def forward(ctx, G, A, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(G, A)
+        return ops.trip_sddmm(G.contiguous(), A.contiguous(), geo)
+
+    @staticmethod
+    def backward(ctx, g):
+        G, A = ctx.saved_tensors
+        g = g.contiguous()
+        return (_SpmmFn.apply(g, A, ctx.geo) if ctx.needs_input_grad[0] else None,
+                _SpmmTFn.apply(g, G, ctx.geo) if ctx.needs_input_grad[1] else None, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the energy as a function of positions and parameters
+# ---------------------------------------------------------------------------------------------------------------------
+def _mlp(seq, x: Tensor) -> Tensor:
+    from ..nn.base import Dense
+
+    for m in seq:
+        x = dense(x, m.weight, m.bias) if isinstance(m, Dense) else m(x)
+    return x
+
+
+def _triplet_weights(geo: _Geo, u: Tensor, G: Tensor) -> Tensor:
+    """w[t, l] = Y_l(u_p . u_q) / max(sqrt(Y^T G_q Y), 1e-12), zero for q == p  (lcaonet.py:179-184 in Gram form)."""
+    n_l = geo.n_l
+    c = (gather(u, geo.tp) * gather(u, geo.tq)).sum(dim=1)
+    ys = [torch.full_like(c, Y0), Y1 * c, Y2A * c * c - Y2B, Y3 * c * (5.0 * c * c - 3.0)][:n_l]
+    y = torch.stack(ys, dim=1)                                               # (T, n_l)
+    Gq = gather(G.reshape(geo.E, n_l * n_l), geo.tq).reshape(-1, n_l, n_l)
+    n2 = torch.einsum("tl,tlm,tm->t", y, Gq, y)
+    inv = torch.rsqrt(torch.clamp_min(n2, 1e-24))
+    return y * inv.unsqueeze(1) * geo.tmask
+
+
+def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_direct_forces: bool = False):
+    """(B, out_size) model output as a twice-differentiable function of pos (N, 3) and of every parameter.
+    x_tab (zdim, H) / cst_pair (zdim^2, D, C): the species tables (model/train.py::species_tables_autograd).
+    with_direct_forces: also return the direct-force head's (N, 3) output (lcaonet.py:303-308)."""
+    geo = _Geo(model, graph)
+    V = model.emb_size_conv
+    vec = gather(pos, geo.dst) - gather(pos, geo.src) + geo.cell_shift
+    dist = vec.norm(dim=1)
+    u = vec / dist.unsqueeze(1)
+    rb = model.rbf.differentiable(dist)                                       # (E, D), p-space
+    x = gather(x_tab, geo.zplan)                                              # (N, H)
+    mask_pair = model.pair_valence_mask(geo.zdim).unsqueeze(-1) if model.add_valence else None
+    for layer in model.int_layers:
+        nw = dense(x, layer.node_weight.weight, layer.node_weight.bias)
+        xs, xk = nw[:, :V], nw[:, V:]
+        gate = torch.sigmoid(xk)
+        w1 = layer.f_node[0].weight
+        Ps = dense(xs, w1[:, :V], layer.f_node[0].bias)
+        Pt = dense(xs, w1[:, V:])
+        Tf = _mlp(layer.f_coeffs, cst_pair)                                   # (zdim^2, D, V or 2V)
+        if model.add_valence:
+            Ac = _ContractFn.apply(rb, Tf[..., :V], geo)
+            Av = _ContractFn.apply(rb, Tf[..., V:] * mask_pair, geo)
+            A, B, Bv = Ac + Av, Ac.sum(dim=1), Av.sum(dim=1)
+        else:
+            A = _ContractFn.apply(rb, Tf, geo)
+            B, Bv = A.sum(dim=1), None
+        Ag = A * gather(gate, geo.src).unsqueeze(1)
+        G = torch.einsum("elv,emv->elm", A, A)
+        tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)
+        ft = dense(tbw, layer.f_three[0].weight)
+        if Bv is None:
+            lw_in = B + B * ft
+        else:
+            lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
+        bw = dense(F.normalize(lw_in, dim=-1), layer.basis_weight.weight)
+        h1 = layer.f_node[1](gather(Ps, geo.src) + gather(Pt, geo.dst))
+        h2 = layer.f_node[3](dense(h1, layer.f_node[2].weight, layer.f_node[2].bias))
+        x = x + dense(scatter_sum(bw * h2, geo.src), layer.out_weight.weight)
+    prop = _mlp(model.out_layer.out_lin, x)
+    batch = graph.get(GraphKeys.Batch_idx)
+    ext = model.out_layer.is_extensive
+    if batch is not None:
+        from .base import num_graphs
+
+        bplan = IndexPlan(batch, num_graphs(graph, batch))
+        out = scatter_sum(prop, bplan)
+        cnt = (bplan.ptr[1:] - bplan.ptr[:-1]).clamp(min=1).to(prop.dtype).unsqueeze(1)
+        if not ext:
+            out = out / cnt
+    else:
+        out = prop.sum(0, keepdim=True) if ext else prop.mean(0, keepdim=True)
+    out = model.pp_layer(out, geo.z, batch, out.shape[0])
+    if not with_direct_forces:
+        return out
+    f = _mlp(model.out_layer.out_lin_force, torch.cat([gather(x, geo.src), gather(x, geo.dst)], dim=-1)) * u
+    return out, scatter_sum(f, geo.src)
+
+
+def forward_exact_forces(model, graph, update_stats: bool = True, tables=None):
+    """(out, force): LCAONet.forward for regress_forces=True, direct_forces=False with BOTH results carrying an autograd
+    graph to every parameter — `force` through the exact second derivative.  Train or eval mode (BatchNorm statistics as
+    in model/train.py)."""
+    from .train import species_tables_autograd
+
+    z = graph[GraphKeys.Z]
+    idx_s, idx_t = graph[GraphKeys.Edge_idx]
+    ops._dev(graph[GraphKeys.Pos], "graph.pos")
+    x_tab, cst_pair = tables if tables is not None else species_tables_autograd(model, z, idx_s, idx_t, update_stats)[:2]
+    with torch.enable_grad():
+        pos = graph[GraphKeys.Pos].detach().float().requires_grad_(True)
+        out = energy(model, graph, pos, x_tab, cst_pair)
+        forces = [-torch.autograd.grad(out[:, i].sum(), pos, create_graph=True)[0] for i in range(model.out_size)]
+    force = forces[0] if model.out_size == 1 else torch.stack(forces, dim=1)
+    return out, force
+
+
+def forward_generic(model, graph, update_stats: bool = True):
+    """LCAONet.forward with an autograd graph for configurations the fused training sweep (model/train.py::LCAOStackFn)
+    does not cover — any activation module (lcaonet/nn/activation.py), any BaseCutoff — through the same primitives."""
+    from .train import species_tables_autograd
+
+    z = graph[GraphKeys.Z]
+    idx_s, idx_t = graph[GraphKeys.Edge_idx]
+    ops._dev(graph[GraphKeys.Pos], "graph.pos")
+    x_tab, cst_pair, _, _ = species_tables_autograd(model, z, idx_s, idx_t, update_stats)
+    if model.regress_forces and not model.direct_forces:
+        return forward_exact_forces(model, graph, update_stats, tables=(x_tab, cst_pair))
+    pos = graph[GraphKeys.Pos].detach().float()
+    return energy(model, graph, pos, x_tab, cst_pair, with_direct_forces=model.regress_forces)

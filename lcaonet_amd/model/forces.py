@@ -172,7 +172,17 @@ def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
     from .lcaonet import EdgeContext
     from .base import BaseMPNN, num_graphs
 
-    _check_supported(model, tables is not None)
+    try:
+        _check_supported(model, tables is not None)
+    except NotImplementedError:
+        if tables is not None or ctx is not None:
+            raise
+        # other activations / user cutoffs: the generic twice-differentiable graph (model/double.py), results detached
+        from .double import forward_exact_forces
+
+        with torch.enable_grad():
+            out, force = forward_exact_forces(model, graph, update_stats=False)
+        return out.detach(), force.detach()
     batch_idx = graph.get(GraphKeys.Batch_idx)
     z, pos = graph[GraphKeys.Z], graph[GraphKeys.Pos]
     idx_s, idx_t = graph[GraphKeys.Edge_idx]

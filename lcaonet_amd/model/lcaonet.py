@@ -20,7 +20,6 @@ cat[x_s, x_t] = x_s W_a^T + x_t W_b^T.
 """
 from __future__ import annotations
 
-import warnings
 from collections.abc import Callable
 from dataclasses import dataclass
 
@@ -566,15 +565,6 @@ class LCAONet(BaseMPNN):
                               or cst_mode != "edge" or precision != "fp32" or edge_context is not None)
             differentiable = (torch.is_grad_enabled() and not inference_only
                               and any(p.requires_grad for p in self.parameters()))
-            if differentiable and not self.training:
-                from .train import unsupported_reason
-
-                why = unsupported_reason(self)
-                if why is not None:   # eval mode: serve the call, say that the result is graph-less
-                    warnings.warn(f"LCAONet.forward: {why}; running the inference pipeline (the result carries no "
-                                  "autograd graph).  Pass differentiable=False or use torch.no_grad() to silence.",
-                                  stacklevel=2)
-                    differentiable = False
         if differentiable:
             from .train import forward_differentiable
 

@@ -10,7 +10,7 @@ Structure (all of it is exact, summation order aside):
     pair-table HIP pipeline of model/lcaonet.py; its backward is the reverse sweep of model/forces.py extended with
     weight gradients.  Weight-gradient products G^T X are plain GEMMs and go through the vendor library (torch.mm).
   * The output heads (N-level MLPs) and the per-graph reduction are torch ops under autograd.
-Not built: double backward (training on autograd forces, create_graph=True).
+Training on autograd forces (create_graph=True) runs the twice-differentiable graph of model/double.py.
 """
 from __future__ import annotations
 
@@ -291,9 +291,12 @@ def forward_differentiable(model, graph, update_stats: bool = True, energy_only:
     energy_only: return the (B, out) property alone (no force head); update_stats as species_tables_autograd."""
     if model.regress_forces and not model.direct_forces and not energy_only:
         return forward_force_training(model, graph)
-    why = unsupported_reason(model)
-    if why is not None:
-        raise NotImplementedError(why)
+    if unsupported_reason(model) is not None and not energy_only:
+        from .double import forward_generic       # e.g. non-SiLU activations: the generic twice-differentiable graph
+
+        return forward_generic(model, graph, update_stats)
+    if unsupported_reason(model) is not None:
+        raise NotImplementedError(unsupported_reason(model))
     z = graph[GraphKeys.Z]
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(graph[GraphKeys.Pos], "graph.pos")
@@ -344,18 +347,17 @@ def forward_differentiable(model, graph, update_stats: bool = True, energy_only:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Training on autograd forces (regress_forces=True, direct_forces=False in train mode; reference lcaonet.py:310-317 with
-# create_graph=True).  The reference differentiates its backward pass a second time.  Here the force loss reaches the
-# parameters through a Hessian-vector product taken by CENTRAL DIFFERENCES of first-order passes:
-#     dL/dtheta (force part) = -d/dtheta [ v . dE/dx ],  v = dL/dF      (F = -dE/dx)
-#                            = -d/dtheta [ E(x + h v) - E(x - h v) ] / (2 h)  + O(h^2)
-# i.e. two more differentiable forwards at displaced positions (same edges, same BatchNorm batch statistics) and their
-# ordinary backward; h puts the largest displacement at 0.01 A.  Measured against the exact double backward through
-# the fp64 oracle: 2e-6 (eval) / 2e-5 (train mode) of each parameter gradient's maximum — inside the 2e-4 bar of the
-# first-order gradient tests (tests/test_gpu_parity.py::test_force_training_*).  It is not the same arithmetic as the
-# reference's, so it can be switched off:  model.force_training = None  makes the combination raise instead.
+# Training on autograd forces (regress_forces=True, direct_forces=False with autograd on; reference lcaonet.py:310-317
+# with create_graph=True).  Default: the EXACT double backward — the energy is assembled from twice-differentiable
+# primitives (model/double.py) and F = -dE/dpos is taken with create_graph=True, so forces carry a real graph in train and
+# eval mode.  `model.force_training = "central-difference"` selects the older cross-check instead: the force loss
+# reaches the parameters through a Hessian-vector product by CENTRAL DIFFERENCES of first-order passes,
+#     dL/dtheta (force part) = -d/dtheta [ E(x + h v) - E(x - h v) ] / (2 h)  + O(h^2),   v = dL/dF,
+# two more differentiable forwards at displaced positions, h putting the largest displacement at 0.01 A (an
+# approximation with a step size: 2e-6 (eval) / 2e-5 (train mode) from the exact result).  `None` makes the
+# combination raise.
 # ---------------------------------------------------------------------------------------------------------------------
-FORCE_TRAINING_MODES = ("central-difference",)
+FORCE_TRAINING_MODES = ("exact", "central-difference")
 _GRAPH_KEYS = (GraphKeys.Z, GraphKeys.Pos, GraphKeys.Edge_idx, GraphKeys.Edge_shift, GraphKeys.Lattice, GraphKeys.Batch_idx)
 
 
@@ -405,8 +407,11 @@ def forward_force_training(model, graph, max_displacement: float = 0.01):
     mode = getattr(model, "force_training", FORCE_TRAINING_MODES[0])
     if mode not in FORCE_TRAINING_MODES:
         raise NotImplementedError(
-            "training on autograd forces: the exact double backward is not built and the central-difference "
-            f"Hessian-vector product is switched off (model.force_training = {mode!r}; allowed: {FORCE_TRAINING_MODES})")
+            f"training on autograd forces is switched off (model.force_training = {mode!r}; allowed: {FORCE_TRAINING_MODES})")
+    if mode == "exact":
+        from .double import forward_exact_forces
+
+        return forward_exact_forces(model, graph)
     out = forward_differentiable(model, graph, True, True)          # energies: exact first-order path, BN stats updated
     z = graph[GraphKeys.Z]
     idx_s, idx_t = graph[GraphKeys.Edge_idx]

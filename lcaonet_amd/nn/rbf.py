@@ -23,17 +23,43 @@ def laguerre_coeffs(n: int, l: int) -> list[int]:
     return [-((-1) ** i) * math.comb(k + a, k - i) * (math.factorial(n + l) // math.factorial(i)) for i in range(k + 1)]
 
 
-def orbital_table(nl_list, r0: float = 0.529) -> Tensor:
+def orbital_table(nl_list, r0: float = 0.529, norms: list[float] | None = None) -> Tensor:
+    """One 12-float row per orbital (include/lcaonet_hip.h: LCAO_ORB_STRIDE).  norms: per-orbital prefactors replacing
+    the all-space normalisation C_nl (integral_norm=True)."""
     rows = []
-    for n, l in nl_list:
+    for i, (n, l) in enumerate(nl_list):
         n, l = int(n), int(l)
         c = laguerre_coeffs(n, l)
         if len(c) > 7 or l > 3:
             raise ValueError(f"orbital (n={n}, l={l}) outside the kernel's table (n-l-1 <= 6, l <= 3)")
         norm = -math.sqrt((2.0 / n / r0) ** 3 * math.factorial(n - l - 1) / 2.0 / n / math.factorial(n + l) ** 3)
+        if norms is not None:
+            norm = norms[i]
         rows.append([2.0 / n / r0, norm, float(l), float(len(c) - 1)] + [float(v) for v in c] + [0.0] * (7 - len(c))
                     + [math.pi * n])
     return torch.tensor(rows, dtype=torch.float64).to(torch.float32)
+
+
+def _sphere_norms(nl_list, r0: float, rc: float, cutoff_net: BaseCutoff) -> list[float]:
+    """integral_norm=True (rbf.py:88-89,107-127): prefactor -2/(n r0) times 1 / (sqrt(int_0^rc (r f(r))^2 dr) + 1e-12), the
+    integral of the cutoff-weighted orbital over the cutoff sphere by adaptive quadrature (fp64)."""
+    from scipy.integrate import quad
+
+    out = []
+    for n, l in nl_list:
+        n, l = int(n), int(l)
+        c = laguerre_coeffs(n, l)
+        pre = -2.0 / n / r0
+
+        def f(r, n=n, l=l, c=c, pre=pre):
+            zeta = 2.0 / n / r0 * r
+            poly = sum(ci * zeta**i for i, ci in enumerate(c))
+            cw = float(cutoff_net.differentiable(torch.tensor([r], dtype=torch.float64)))
+            return cw * pre * poly * zeta**l * math.exp(-zeta / 2.0)
+
+        integral = quad(lambda r: (r * f(r)) ** 2, 0.0, rc)[0]
+        out.append(pre / (math.sqrt(integral) + 1e-12))
+    return out
 
 
 class BaseRadialBasis(nn.Module):
@@ -62,6 +88,26 @@ class BaseRadialBasis(nn.Module):
     def forward(self, r: Tensor) -> Tensor:
         return self._eval(r)
 
+    def differentiable(self, r: Tensor) -> Tensor:
+        """The same basis from tensor ops under autograd (any order of derivative) — the (E, D) radial table is tiny
+        next to the (E, V) work, and the exact double backward of force training (model/double.py) needs R, R' and R''."""
+        tab = self.orb_table.to(r.dtype)
+        cw = self.cutoff_net.differentiable(r)
+        cols = []
+        for d in range(tab.shape[0]):
+            row = tab[d]
+            if self.rbf_kind == "hydrogen":
+                zeta = row[0] * r
+                k, l = int(row[3]), int(row[2])
+                poly = torch.full_like(r, float(row[4 + k]))
+                for i in range(k - 1, -1, -1):
+                    poly = poly * zeta + row[4 + i]
+                zl = torch.ones_like(r) if l == 0 else zeta**l
+                cols.append(cw * row[1] * poly * zl * torch.exp(-0.5 * zeta))
+            else:
+                cols.append(cw * torch.sin(row[11] / self.cutoff * r) / r)
+        return torch.stack(cols, dim=1)
+
 
 class HydrogenRadialBasis(BaseRadialBasis):
     rbf_kind = "hydrogen"
@@ -69,11 +115,11 @@ class HydrogenRadialBasis(BaseRadialBasis):
     def __init__(self, cutoff: float, elec_info: ElecInfo, cutoff_net: BaseCutoff, bohr_radius: float = 0.529,
                  integral_norm: bool = False):
         super().__init__(cutoff, elec_info, cutoff_net)
-        if integral_norm:
-            raise NotImplementedError("integral_norm=True (unreachable through LCAONet) is not built yet")
         self.bohr_radius = bohr_radius
         self.integral_norm = integral_norm
-        self.register_buffer("orb_table", orbital_table(elec_info.nl_list.tolist(), bohr_radius), persistent=False)
+        nl = elec_info.nl_list.tolist()
+        norms = _sphere_norms(nl, bohr_radius, cutoff, cutoff_net) if integral_norm else None
+        self.register_buffer("orb_table", orbital_table(nl, bohr_radius, norms), persistent=False)
 
 
 class SphericalBesselRadialBasis(BaseRadialBasis):

@@ -230,6 +230,18 @@ class OracleConfig:
     extra: dict = field(default_factory=dict)
 
 
+def _act(cfg):
+    """The activation module LCAONet builds once and shares between all its MLPs (lcaonet.py:372 via
+    utils/resolve.py:66-76): torch.nn activations by name plus lcaonet/nn/activation.py:36-60 (ShiftedSoftplus =
+    softplus(x) - ln 2).  Constructor argument `activation`, default "SiLU"; carried in cfg.extra."""
+    name = str(cfg.extra.get("activation", "SiLU")).lower()
+    table = {"silu": F.silu, "shiftedsoftplus": lambda x: F.softplus(x) - math.log(2.0), "tanh": torch.tanh,
+             "elu": F.elu, "relu": F.relu, "sigmoid": torch.sigmoid, "softplus": F.softplus}
+    if name not in table:
+        raise ValueError(f"activation {name} not restated")
+    return table[name]
+
+
 def _lin(x: Tensor, sd: dict, key: str) -> Tensor:
     return F.linear(x, sd[key + ".weight"], sd.get(key + ".bias"))
 
@@ -258,13 +270,14 @@ def embedding(sd: dict, cfg: OracleConfig, z: Tensor, idx_s: Tensor, idx_t: Tens
     else:
         coeff_e = e_embed
         node_in = node_z
-    h = F.silu(_lin(node_in, sd, p + "node_embed.f_enc.0"))
-    h = F.silu(_lin(h, sd, p + "node_embed.f_enc.2"))
+    act = _act(cfg)
+    h = act(_lin(node_in, sd, p + "node_embed.f_enc.0"))
+    h = act(_lin(h, sd, p + "node_embed.f_enc.2"))
     x = _bn(h, sd, p + "node_embed.bn", cfg.training)
     # coefficients
     zz = _lin(torch.cat([coeff_z[idx_s], coeff_z[idx_t]], dim=-1), sd, p + "coeff_embed.f_z.0")
-    fe = F.silu(_lin(coeff_e, sd, p + "coeff_embed.f_e.0"))
-    fe = F.silu(_lin(fe, sd, p + "coeff_embed.f_e.2"))[idx_t]
+    fe = act(_lin(coeff_e, sd, p + "coeff_embed.f_e.0"))
+    fe = act(_lin(fe, sd, p + "coeff_embed.f_e.2"))[idx_t]
     coeff = fe + fe * zz.unsqueeze(1)
     cst = _bn(coeff.reshape(coeff.size(0), -1), sd, p + "coeff_embed.bn", cfg.training).reshape(coeff.size())
     return x, cst
@@ -279,8 +292,9 @@ def interaction(sd: dict, prefix: str, cfg: OracleConfig, x: Tensor, cst: Tensor
     x_before = x
     N = x.size(0)
     x, xk = torch.chunk(_lin(x, sd, prefix + "node_weight"), 2, dim=-1)  # :167
-    cst = F.silu(_lin(cst, sd, prefix + "f_coeffs.0"))  # :170
-    cst = F.silu(_lin(cst, sd, prefix + "f_coeffs.2"))
+    act = _act(cfg)
+    cst = act(_lin(cst, sd, prefix + "f_coeffs.0"))  # :170
+    cst = act(_lin(cst, sd, prefix + "f_coeffs.2"))
     cks = cst[edge_idx_ks]  # :173
     if cfg.add_valence:
         cks, cks_valence = torch.chunk(cks, 2, dim=-1)
@@ -304,8 +318,8 @@ def interaction(sd: dict, prefix: str, cfg: OracleConfig, x: Tensor, cst: Tensor
     lcao_w = F.normalize(lcao_w, dim=-1)  # :204
     if trace is not None:
         trace["lcao_w"] = lcao_w
-    h = F.silu(_lin(torch.cat([x[idx_s], x[idx_t]], dim=-1), sd, prefix + "f_node.0"))  # :209
-    h = F.silu(_lin(h, sd, prefix + "f_node.2"))
+    h = act(_lin(torch.cat([x[idx_s], x[idx_t]], dim=-1), sd, prefix + "f_node.0"))  # :209
+    h = act(_lin(h, sd, prefix + "f_node.2"))
     msg = _lin(lcao_w, sd, prefix + "basis_weight") * h
     return x_before + _lin(scatter_sum(msg, idx_s, N), sd, prefix + "out_weight")  # :207-214
 
@@ -314,8 +328,9 @@ def out_layer(sd: dict, cfg: OracleConfig, x: Tensor, batch: Tensor | None, idx_
               edge_vec: Tensor, n_graphs: int | None = None):
     """LCAOOut.forward lcaonet.py:271-319 (autograd forces: handled by the caller)."""
     p = "out_layer.out_lin."
-    prop = F.silu(_lin(x, sd, p + "0"))
-    prop = F.silu(_lin(prop, sd, p + "2"))
+    act = _act(cfg)
+    prop = act(_lin(x, sd, p + "0"))
+    prop = act(_lin(prop, sd, p + "2"))
     prop = _lin(prop, sd, p + "4")
     if batch is not None:
         B = int(batch.max().item()) + 1 if n_graphs is None else n_graphs
@@ -325,8 +340,8 @@ def out_layer(sd: dict, cfg: OracleConfig, x: Tensor, batch: Tensor | None, idx_
     if not (cfg.regress_forces and cfg.direct_forces):
         return prop
     p = "out_layer.out_lin_force."
-    f = F.silu(_lin(torch.cat([x[idx_s], x[idx_t]], dim=-1), sd, p + "0"))
-    f = F.silu(_lin(f, sd, p + "2"))
+    f = act(_lin(torch.cat([x[idx_s], x[idx_t]], dim=-1), sd, p + "0"))
+    f = act(_lin(f, sd, p + "2"))
     f = _lin(f, sd, p + "4") * edge_vec
     return prop, scatter_sum(f, idx_s, x.size(0))
 

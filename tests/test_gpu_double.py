@@ -1,0 +1,149 @@
+"""Exact double backward (lcaonet_amd/model/double.py): training on autograd forces as the reference does it
+(lcaonet/model/lcaonet.py:310-317, torch.autograd.grad(create_graph=True); tests/model/test_lcaonet.py:219-243) — against
+torch.autograd through the fp64 oracle.  No step size anywhere: the HIP primitives are linear / bilinear and their
+backward passes are built from the same family, so autograd differentiates the force computation itself."""
+import pytest
+import torch
+
+from conftest import relerr
+from oracle import restatement as O
+from test_gpu_parity import _ocfg, _random_model
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _oracle_force_loss_grads(sd, kw, g_cpu, training, w_e=0.1):
+    cfg = _ocfg({**kw, "rbf_type": kw.get("rbf_type", "hydrogen"), "training": training})
+    sdg = {k: (v.clone().double().requires_grad_("running_" not in k) if v.is_floating_point() else v.clone())
+           for k, v in sd.items()}
+    e_ref, f_ref = O.forward(sdg, cfg, g_cpu, dtype=torch.float64)
+    t_e, t_f = torch.ones_like(e_ref), torch.full_like(f_ref, 0.05)
+    (w_e * ((e_ref - t_e) ** 2).mean() + ((f_ref - t_f) ** 2).mean()).backward()
+    return e_ref.detach(), f_ref.detach(), t_e, t_f, {k: v.grad for k, v in sdg.items() if torch.is_tensor(v) and v.grad is not None}
+
+
+def _check_param_grads(m, want, tol):
+    checked, worst = 0, 0.0
+    for name, p in m.named_parameters():
+        ref = want.get(name)
+        if ref is None or float(ref.abs().max()) < 1e-12:
+            continue
+        assert p.grad is not None, name
+        got, ref = (p.grad[1:], ref[1:]) if "e_embeds" in name else (p.grad, ref)     # padding row: see test_gpu_parity
+        if float(ref.abs().max()) < 1e-12:
+            continue
+        err = relerr(got, ref)
+        worst = max(worst, err)
+        assert err <= tol, (name, err)
+        checked += 1
+    return checked, worst
+
+
+@pytest.mark.parametrize("case", ["v64_eval", "v64_train", "v128_out2_mean", "v48_valence_poly"])
+def test_exact_force_training_vs_oracle_double_backward(dev, case):
+    """Parameter gradients of an energy + force loss, forces = -dE/dpos with create_graph=True: every tensor within 2e-5
+    of the fp64 oracle's double backward (the central-difference cross-check needed 2e-4)."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=32, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=5.0, regress_forces=True,
+              direct_forces=False)
+    training = case == "v64_train"
+    if case == "v128_out2_mean":
+        kw.update(emb_size_coeff=128, emb_size_conv=128, out_size=2, is_extensive=False)
+    elif case == "v48_valence_poly":
+        kw.update(emb_size_coeff=24, emb_size_conv=48, add_valence=True, cutoff_net="polynomial", n_interaction=3)
+    m, sd = _random_model(dev, 777, grad=True, **kw)
+    m.train(training)
+    g = random_periodic_cells(2, 10, 6.0, 0.99 * 5.0, seed=31)
+    e_ref, f_ref, t_e, t_f, want = _oracle_force_loss_grads(sd, kw, g.to_dict(), training)
+    assert getattr(m, "force_training", "exact") == "exact"
+    e, f = m(g.to(dev))                                   # autograd on + parameters require grad: the differentiable path
+    assert e.requires_grad and f.requires_grad and f.grad_fn is not None
+    assert relerr(e.detach(), e_ref) <= 2e-5 and relerr(f.detach(), f_ref) <= 5 * TOL and f.shape == f_ref.shape
+    loss = 0.1 * ((e - t_e.to(dev).float()) ** 2).mean() + ((f - t_f.to(dev).float()) ** 2).mean()
+    loss.backward()
+    checked, worst = _check_param_grads(m, want, 2e-5)
+    assert checked > 25, checked
+    print(f"exact force training [{case}]: worst parameter-gradient deviation {worst:.2e} over {checked} tensors")
+    if training:
+        assert int(m.emb_layer.coeff_embed.bn.num_batches_tracked) == 1
+
+
+def test_eval_mode_forces_are_differentiable_and_match_the_inference_sweep(dev):
+    """Eval mode with autograd on returns forces WITH a graph (the reference's create_graph=True), equal to the fast
+    graph-less inference sweep (frozen parameters / torch.no_grad()); the force graph reaches pos-independent parameters
+    only through the second derivative, and a second call is bitwise reproducible."""
+    from lcaonet_amd.data.synthetic import random_molecule_batch
+    kw = dict(emb_size=64, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=6.0, max_z=10,
+              regress_forces=True, direct_forces=False)
+    m, _ = _random_model(dev, 31, grad=True, **kw)
+    g = random_molecule_batch(5, 3, 9, cutoff_graph=0.99 * 6.0, seed=8, device=dev)
+    e, f = m(g)
+    assert f.requires_grad and e.requires_grad and not m.training
+    with torch.no_grad():
+        e0, f0 = m(g)
+    assert not f0.requires_grad
+    assert relerr(e.detach(), e0) <= 5e-6 and relerr(f.detach(), f0) <= 2e-5
+    gW = torch.autograd.grad((f ** 2).sum(), m.out_layer.out_lin[4].weight, retain_graph=True)[0]
+    assert float(gW.abs().max()) > 0                     # d|F|^2 / d(last head weight): pure second-derivative path
+    e2, f2 = m(g)
+    assert torch.equal(f2.detach(), f.detach())
+
+
+@pytest.mark.parametrize("activation", ["ShiftedSoftplus", "Tanh", "ELU"])
+def test_other_activations_in_the_differentiable_paths(dev, activation):
+    """lcaonet/nn/activation.py / utils/resolve.py:66: activations other than SiLU in training and in autograd forces
+    (the generic twice-differentiable graph serves them; the fused sweeps are SiLU-only)."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=4.5, activation=activation)
+    g = random_periodic_cells(2, 9, 6.0, 0.99 * 4.5, seed=13)
+    # energies + parameter gradients
+    m, sd = _random_model(dev, 801, grad=True, **kw)
+    okw = {k: v for k, v in kw.items() if k != "activation"}
+    sdg = {k: (v.clone().double().requires_grad_("running_" not in k) if v.is_floating_point() else v.clone())
+           for k, v in sd.items()}
+    want = O.forward(sdg, _ocfg({**okw, "rbf_type": "hydrogen", "extra": {"activation": activation}}), g.to_dict(),
+                     dtype=torch.float64)
+    want.sum().backward()
+    out = m(g.to(dev))
+    assert out.requires_grad and relerr(out.detach(), want.detach()) <= 2e-5
+    out.sum().backward()
+    checked, worst = _check_param_grads(m, {k: v.grad for k, v in sdg.items() if torch.is_tensor(v) and v.grad is not None}, 2e-4)
+    assert checked > 20
+    # autograd forces at inference (no graph wanted): served by the same graph, detached
+    kwf = dict(kw, regress_forces=True, direct_forces=False)
+    mf, sdf = _random_model(dev, 802, **kwf)
+    okwf = {k: v for k, v in kwf.items() if k != "activation"}
+    wout, wforce = O.forward(sdf, _ocfg({**okwf, "rbf_type": "hydrogen", "extra": {"activation": activation}}), g.to_dict(),
+                             dtype=torch.float64)
+    o, f = mf(g.to(dev))
+    assert not f.requires_grad
+    assert relerr(o, wout.detach()) <= 2e-5 and relerr(f, wforce.detach()) <= 5 * TOL
+
+
+def test_trip_bilinear_family_is_consistent(dev):
+    """csrc/lcao_double.hip: spmm / spmm_t / sddmm against dense per-node einsums, and <spmm(w, A), G> = <w, sddmm(G, A)>
+    = <A, spmm_t(w, G)> (each op is the adjoint of the others in one argument)."""
+    from lcaonet_amd import ops
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import LCAONet
+    from lcaonet_amd.model.double import _Geo
+    g = random_periodic_cells(2, 12, 6.0, 0.99 * 4.5, seed=3).to(dev)
+    for V, n_l, max_z in ((48, 3, 36), (128, 2, 10), (200, 4, 96)):
+        m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=V, n_interaction=1, cutoff=4.5, max_z=max(max_z, 36)).to(dev)
+        geo = _Geo(m, g)
+        geo.n_l = n_l
+        E, T = geo.E, geo.T
+        gen = torch.Generator(device="cpu").manual_seed(V)
+        w = torch.randn(T, n_l, generator=gen).to(dev)
+        A = torch.randn(E, n_l, V, generator=gen).to(dev)
+        G = torch.randn(E, V, generator=gen).to(dev)
+        tp, tq = geo.tp.idx, geo.tq.idx
+        want = torch.zeros(E, V, device=dev, dtype=torch.float64).index_add_(
+            0, tp, torch.einsum("tl,tlv->tv", w.double(), A.double()[tq]))
+        assert relerr(ops.trip_spmm(w, A, geo), want) <= 2e-6
+        want_t = torch.zeros(E, n_l, V, device=dev, dtype=torch.float64).index_add_(
+            0, tq, w.double().unsqueeze(2) * G.double()[tp].unsqueeze(1))
+        assert relerr(ops.trip_spmm_t(w, G, geo), want_t) <= 2e-6
+        want_d = torch.einsum("tv,tlv->tl", G.double()[tp], A.double()[tq])
+        assert relerr(ops.trip_sddmm(G, A, geo), want_d) <= 2e-6
