@@ -60,6 +60,14 @@ int lcao_cutoff(const float* r, int64_t n, int kind, float rc, float* out, void*
 int lcao_radial_basis(const float* r, int64_t n_edges, int n_orb, const float* orb_table, int rbf_kind,
                       int cutoff_kind, float rc, float* rb, void* stream);
 
+/* a1 + a4 + a5 fused, one thread per edge of p-space (order / src_p / dst_p from lcao_build_csr): the outputs of
+ * lcao_edge_geometry (dist, uvec, caller's edge order) and lcao_radial_basis (rb (E, D), caller's order) plus uvec_p, the
+ * unit vectors in p-space.  Same arithmetic as the two separate calls. */
+int lcao_edge_geometry_basis(const float* pos, const int32_t* order, const int32_t* src_p, const int32_t* dst_p,
+                             const float* shift, const float* lattice, const int64_t* batch /*nullable*/, int64_t n_edges,
+                             int n_orb, const float* orb_table, int rbf_kind, int cutoff_kind, float rc, float* dist,
+                             float* uvec, float* uvec_p, float* rb, void* stream);
+
 /* a6  SphericalHarmonicsBasis.forward (lcaonet/nn/shbf.py:75-87): costheta (T) -> shb (T, D), Y_l^0, l = l_of_d[d] */
 int lcao_sph_basis(const float* costheta, int64_t n, int n_orb, const int32_t* l_of_d, float* shb, void* stream);
 

@@ -19,6 +19,7 @@ SIGNATURES = {
     "lcao_edge_geometry": [P, P, P, P, P, P, L, P, P, P],
     "lcao_cutoff": [P, L, I, F, P, P],
     "lcao_radial_basis": [P, L, I, P, I, I, F, P, P],
+    "lcao_edge_geometry_basis": [P, P, P, P, P, P, P, L, I, P, I, I, F, P, P, P, P, P],
     "lcao_sph_basis": [P, L, I, P, P, P],
     "lcao_triplet_angles": [P, P, P, L, P, P],
     "lcao_build_csr_workspace_bytes": [L, L],

@@ -104,6 +104,61 @@ extern "C" int lcao_radial_basis(const float* r, int64_t n_edges, int n_orb, con
   return lcao_launch_status();
 }
 
+// a1 + a4 + a5 in ONE pass over the edges in p-space (sorted by centre): pos -> dist, unit vectors and the radial basis
+// with no `dist` round trip through HBM, and the unit vectors written a second time directly in p-space (what
+// lcao_triplet_gemm reads), which removes the separate row permutation.  Arithmetic identical to lcao_edge_geometry +
+// lcao_radial_basis.  Algorithmic bytes per edge: 12 (3 int32) + 12 (shift) + 24 (pos, cache-resident) read; 4 + 12 + 12 +
+// 4 D written.
+__global__ void k_edge_geometry_basis(const float* __restrict__ pos, const int32_t* __restrict__ order,
+                                      const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p,
+                                      const float* __restrict__ shift, const float* __restrict__ lattice,
+                                      const int64_t* __restrict__ batch, int64_t E, int D,
+                                      const float* __restrict__ tab, int rbf_kind, int cutoff_kind, float rc,
+                                      float* __restrict__ dist, float* __restrict__ uvec, float* __restrict__ uvec_p,
+                                      float* __restrict__ rb) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= E) return;
+  const int64_t e = order[p];
+  const int64_t s = src_p[p], t = dst_p[p];
+  const float* L = lattice + 9 * (batch ? batch[s] : 0);
+  const float sx = shift[3 * e], sy = shift[3 * e + 1], sz = shift[3 * e + 2];
+  float v[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float off = sx * L[j] + sy * L[3 + j] + sz * L[6 + j];
+    v[j] = (pos[3 * t + j] - pos[3 * s + j]) + off;
+  }
+  const float d = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float ux = v[0] / d, uy = v[1] / d, uz = v[2] / d;
+  dist[e] = d;
+  uvec[3 * e] = ux; uvec[3 * e + 1] = uy; uvec[3 * e + 2] = uz;
+  uvec_p[3 * p] = ux; uvec_p[3 * p + 1] = uy; uvec_p[3 * p + 2] = uz;
+  const float cw = lcao_cutoff_eval(d, rc, cutoff_kind);
+  for (int k = 0; k < D; ++k) {
+    const float* row = tab + k * LCAO_ORB_STRIDE;
+    float val;
+    if (rbf_kind == LCAO_RBF_HYDROGEN) val = lcao_hydrogen_rnl(d, cw, row);
+    else val = cw * sinf(row[11] * d / rc) / d;
+    rb[e * D + k] = val;
+  }
+}
+
+extern "C" int lcao_edge_geometry_basis(const float* pos, const int32_t* order, const int32_t* src_p, const int32_t* dst_p,
+                                        const float* shift, const float* lattice, const int64_t* batch, int64_t n_edges,
+                                        int n_orb, const float* orb_table, int rbf_kind, int cutoff_kind, float rc,
+                                        float* dist, float* uvec, float* uvec_p, float* rb, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (n_orb <= 0 || rbf_kind < 0 || rbf_kind > 1 || cutoff_kind < 0 || cutoff_kind > 3) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(pos); LCAO_CHECK_PTR(order); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(shift);
+  LCAO_CHECK_PTR(lattice); LCAO_CHECK_PTR(orb_table); LCAO_CHECK_PTR(dist); LCAO_CHECK_PTR(uvec); LCAO_CHECK_PTR(uvec_p);
+  LCAO_CHECK_PTR(rb);
+  hipLaunchKernelGGL(k_edge_geometry_basis, dim3(lcao_blocks(n_edges, 256)), dim3(256), 0, (hipStream_t)stream, pos, order,
+                     src_p, dst_p, shift, lattice, batch, n_edges, n_orb, orb_table, rbf_kind, cutoff_kind, rc, dist, uvec,
+                     uvec_p, rb);
+  return lcao_launch_status();
+}
+
 __global__ void k_sph_basis(const float* __restrict__ c, int64_t n, int D, const int32_t* __restrict__ l_of_d,
                             float* __restrict__ out) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;

@@ -580,6 +580,25 @@ class LCAONet(BaseMPNN):
         ValenceMask.forward(z, idx_t))."""
         return self.valence_mask.valence[:zdim].to(torch.float32).repeat(zdim, 1).contiguous()
 
+    @torch.no_grad()
+    def geometry_and_basis(self, graph, ctx: EdgeContext):
+        """(dist, uvec, rb): calc_atomic_distances (base.py:15-43; writes edge_dist / edge_vec into the graph as the
+        reference does) and the radial basis — ONE launch for the built-in bases and cutoffs, which also leaves the unit
+        vectors in p-space in the context."""
+        kind = getattr(self.rbf.cutoff_net, "kind", None)
+        rkind = getattr(self.rbf, "rbf_kind", None)
+        if kind is None or rkind is None or type(self.rbf).forward is not BaseRadialBasis.forward:
+            graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)      # user-defined basis / envelope
+            dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
+            return dist, uvec, self.rbf(dist)
+        ops._dev(graph[GraphKeys.Pos], "graph.pos")
+        dist, uvec, uvec_p, rb = ops.edge_geometry_basis(
+            graph[GraphKeys.Pos], ctx.order, ctx.src_p, ctx.dst_p, graph[GraphKeys.Edge_shift], graph[GraphKeys.Lattice],
+            graph.get(GraphKeys.Batch_idx), self.rbf.orb_table, rkind, kind, self.cutoff)
+        graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st] = dist, uvec
+        ctx._uvec_p, ctx._uvec_src = uvec_p, uvec
+        return dist, uvec, rb
+
     def _gathers_cst(self, fused: bool | None, precision: str) -> bool:
         """Eval mode with the fused coefficient kernel on every layer: the coefficient rows are gathered in-kernel."""
         if self.training or fused is False:
@@ -608,12 +627,9 @@ class LCAONet(BaseMPNN):
         # edge_context: the index structures of this edge list built earlier (EdgeContext.build) — they do not depend on
         # positions, so a caller that keeps the edge list (model/capture.py) builds them once
         ctx = edge_context if edge_context is not None else EdgeContext.build(edge_index, N)
-        graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
-        dist, uvec = graph[GraphKeys.Edge_dist], graph[GraphKeys.Edge_vec_st]
+        dist, uvec, rb = self.geometry_and_basis(graph, ctx)
         if materialize_triplets:
             graph = self.calc_3body_angles(self.get_triplets(graph))
-
-        rb = self.rbf(dist)
         pair = cst_row = None
         if cst_mode == "pair":
             # cst_mode="pair": species-pair table instead of the per-edge (E, D, C) tensor.  Same

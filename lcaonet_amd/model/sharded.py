@@ -14,7 +14,6 @@ from .. import ops
 from ..data.keys import GraphKeys
 from ..nn.base import run_mlp
 from ..nn.scatter import scatter
-from .base import BaseMPNN
 
 
 class ShardedForward:
@@ -27,9 +26,7 @@ class ShardedForward:
         z = graph[GraphKeys.Z]
         self.z = z
         self.ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], z.size(0))
-        graph = BaseMPNN.calc_atomic_distances(graph, return_vec=True)
-        self.uvec = graph[GraphKeys.Edge_vec_st]
-        self.rb = model.rbf(graph[GraphKeys.Edge_dist])
+        _, self.uvec, self.rb = model.geometry_and_basis(graph, self.ctx)
         # static inputs: every local row (ghosts included) is known without an exchange
         self.cst_row = None
         if model._gathers_cst(fused, "fp32"):

@@ -142,6 +142,21 @@ def radial_basis(r: Tensor, orb_table: Tensor, rbf_kind: str, cutoff_kind: str, 
     return rb
 
 
+def edge_geometry_basis(pos, order, src_p, dst_p, shift, lattice, batch, orb_table, rbf_kind: str, cutoff_kind: str, rc: float):
+    """(dist (E), uvec (E,3), uvec_p (E,3), rb (E,D)): edge_geometry + radial_basis in one launch, plus the unit vectors
+    in p-space (csrc/lcao_generic.hip::k_edge_geometry_basis)."""
+    pos, shift, lattice = _f32(pos, "pos"), _f32(shift, "edge_shift"), _f32(lattice, "lattice")
+    orb_table = _f32(orb_table, "orb_table")
+    batch = _i64(batch) if batch is not None else None
+    E, D, dev = order.numel(), orb_table.shape[0], pos.device
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    dist, uvec, uvec_p, rb = new(E), new(E, 3), new(E, 3), new(E, D)
+    _call("lcao_edge_geometry_basis", _p(pos), _p(_i32(order)), _p(_i32(src_p)), _p(_i32(dst_p)), _p(shift), _p(lattice),
+          _p(batch), E, D, _p(orb_table), RBF_KINDS[rbf_kind], CUTOFF_KINDS[cutoff_kind], float(rc), _p(dist), _p(uvec),
+          _p(uvec_p), _p(rb), _stream())
+    return dist, uvec, uvec_p, rb
+
+
 def sph_basis(costheta: Tensor, l_of_d: Tensor) -> Tensor:
     c = _f32(costheta, "costheta")
     l_of_d = _i32(l_of_d, "l_of_d")
