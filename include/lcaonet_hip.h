@@ -83,7 +83,17 @@ int lcao_triplet_angles(const float* uvec, const int64_t* e_st, const int64_t* e
 size_t lcao_build_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
 int lcao_build_csr(const int64_t* idx_s, const int64_t* idx_t, int64_t n_edges, int64_t n_nodes, int32_t* order,
                    int32_t* src_p, int32_t* dst_p, int32_t* out_ptr, int32_t* in_ptr, int32_t* in_pos, int32_t* src_o,
-                   int32_t* dst_o, void* workspace, size_t ws_bytes, void* stream);
+                   int32_t* dst_o, void* workspace, size_t ws_bytes,
+                   int32_t* err_flag /* device int32, nullable: bit LCAO_FLAG_EDGE_INDEX is OR-ed in when an endpoint is
+                                        outside [0, n_nodes) (the offending index is clamped) */,
+                   void* stream);
+
+/* Sync-free index validation (the reference raises IndexError from nn.Embedding / tensor indexing): out[i] = v[i] clamped to
+ * [lo, hi]; any value outside the range ORs `bit` into *err_flag.  The host reads the flag when it next synchronises. */
+#define LCAO_FLAG_EDGE_INDEX 1
+#define LCAO_FLAG_ATOMIC_NUMBER 2
+int lcao_checked_index(const int64_t* v, int64_t n, int64_t lo, int64_t hi, int bit, int64_t* out, int32_t* err_flag,
+                       void* stream);
 
 /* SURVEY 8f-1  periodic cell-list neighbour search on the device: what lcaonet/data/convert.py:124-129 obtains from
  * ase.neighbor_list("ijdS") on the CPU.  `graphs`: one 32-word record per graph {lattice[9], inverse[9], bins[3],

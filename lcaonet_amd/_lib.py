@@ -23,7 +23,8 @@ SIGNATURES = {
     "lcao_sph_basis": [P, L, I, P, P, P],
     "lcao_triplet_angles": [P, P, P, L, P, P],
     "lcao_build_csr_workspace_bytes": [L, L],
-    "lcao_build_csr": [P, P, L, L, P, P, P, P, P, P, P, P, P, c_size_t, P],
+    "lcao_build_csr": [P, P, L, L, P, P, P, P, P, P, P, P, P, c_size_t, P, P],
+    "lcao_checked_index": [P, L, L, L, I, P, P, P],
     "lcao_nl_workspace_bytes": [L],
     "lcao_nl_bin_sort": [P, P, P, L, L, P, P, P, P, P, c_size_t, P],
     "lcao_nl_search": [P, P, P, P, P, P, L, F, I, P, P, P, P, P, P, P],

@@ -14,13 +14,46 @@
 
 #include "lcao_common.h"
 
-__global__ void k_csr_convert(const int64_t* __restrict__ idx_s, const int64_t* __restrict__ idx_t, int64_t E,
-                              int32_t* __restrict__ src_o, int32_t* __restrict__ dst_o, int32_t* __restrict__ iota) {
+// int64 -> int32 with a range check: an endpoint outside [0, N) (the reference raises an IndexError for it) sets bit 0 of
+// *err and is clamped, so that no later kernel reads out of bounds; the caller turns the flag into an exception.
+__global__ void k_csr_convert(const int64_t* __restrict__ idx_s, const int64_t* __restrict__ idx_t, int64_t E, int64_t N,
+                              int32_t* __restrict__ src_o, int32_t* __restrict__ dst_o, int32_t* __restrict__ iota,
+                              int32_t* __restrict__ err) {
   int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= E) return;
-  src_o[e] = (int32_t)idx_s[e];
-  dst_o[e] = (int32_t)idx_t[e];
+  int64_t s = idx_s[e], t = idx_t[e];
+  if (s < 0 || s >= N || t < 0 || t >= N) {
+    if (err) atomicOr(err, LCAO_FLAG_EDGE_INDEX);
+    s = min(max(s, (int64_t)0), N - 1);
+    t = min(max(t, (int64_t)0), N - 1);
+  }
+  src_o[e] = (int32_t)s;
+  dst_o[e] = (int32_t)t;
   iota[e] = (int32_t)e;
+}
+
+// out[i] = clamp(v[i], lo, hi); a value outside [lo, hi] sets `bit` of *err (atomic numbers: embed.py:41 indexes z - 1)
+__global__ void k_checked_index(const int64_t* __restrict__ v, int64_t n, int64_t lo, int64_t hi, int bit,
+                                int64_t* __restrict__ out, int32_t* __restrict__ err) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t x = v[i];
+  if (x < lo || x > hi) {
+    if (err) atomicOr(err, bit);
+    x = min(max(x, lo), hi);
+  }
+  out[i] = x;
+}
+
+extern "C" int lcao_checked_index(const int64_t* v, int64_t n, int64_t lo, int64_t hi, int bit, int64_t* out, int32_t* err,
+                                  void* stream) {
+  LCAO_CHECK_SIZE(n);
+  if (lo > hi || bit <= 0) return LCAO_ERR_INVALID;
+  if (n == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(v); LCAO_CHECK_PTR(out);
+  hipLaunchKernelGGL(k_checked_index, dim3(lcao_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, v, n, lo, hi, bit, out,
+                     err);
+  return lcao_launch_status();
 }
 
 __global__ void k_csr_gather(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int64_t E,
@@ -64,7 +97,7 @@ extern "C" size_t lcao_build_csr_workspace_bytes(int64_t n_edges, int64_t n_node
 extern "C" int lcao_build_csr(const int64_t* idx_s, const int64_t* idx_t, int64_t n_edges, int64_t n_nodes,
                               int32_t* order, int32_t* src_p, int32_t* dst_p, int32_t* out_ptr, int32_t* in_ptr,
                               int32_t* in_pos, int32_t* src_o, int32_t* dst_o, void* workspace, size_t ws_bytes,
-                              void* stream) {
+                              int32_t* err_flag, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   LCAO_CHECK_SIZE(n_nodes);
   LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(in_ptr);
@@ -84,7 +117,8 @@ extern "C" int lcao_build_csr(const int64_t* idx_s, const int64_t* idx_t, int64_
   void* temp = (char*)workspace + 2 * e4;
   size_t temp_bytes = ws_bytes - 2 * e4;
   const unsigned nb = lcao_blocks(n_edges, 256);
-  hipLaunchKernelGGL(k_csr_convert, dim3(nb), dim3(256), 0, st, idx_s, idx_t, n_edges, src_o, dst_o, iota);
+  hipLaunchKernelGGL(k_csr_convert, dim3(nb), dim3(256), 0, st, idx_s, idx_t, n_edges, n_nodes, src_o, dst_o, iota,
+                     err_flag);
   // stable sort by centre: keys src_o -> src_p, values iota -> order
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, src_o, src_p, iota, order, (size_t)n_edges, 0, bits, st);
   if (e != hipSuccess) return int(e);

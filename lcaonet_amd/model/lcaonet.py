@@ -30,7 +30,7 @@ from torch import Tensor
 from .. import ops
 from ..atomistic.info import ElecInfo
 from ..data.keys import GraphKeys
-from ..nn.base import Dense, act_code, run_mlp
+from ..nn.base import Dense, act_code, inference_only, run_mlp
 from ..nn.cutoff import BaseCutoff
 from ..nn.embed import EmbedCoeffs, EmbedElec, EmbedNode, EmbedZ, ValenceMask
 from ..nn.post import PostProcess
@@ -200,7 +200,7 @@ class LCAOInteraction(nn.Module):
         self.out_weight = Dense(emb_size_conv, emb_size, False, weight_init)
 
     # ------------------------------------------------------------------ reference operator signature
-    @torch.no_grad()
+    @inference_only
     def forward(self, x: Tensor, cst: Tensor, valence_mask: Tensor | None, rb: Tensor, shb: Tensor, idx_s: Tensor,
                 idx_t: Tensor, tri_idx_k: Tensor, edge_idx_ks: Tensor, edge_idx_st: Tensor) -> Tensor:
         """Literal operator: arbitrary cst / shb / triplet lists as in the reference (lcaonet.py:130-142).
@@ -405,7 +405,7 @@ class LCAOOut(nn.Module):
                 Dense(emb_size // 2, 1, False, weight_init),
             )
 
-    @torch.no_grad()
+    @inference_only
     def forward(self, x: Tensor, batch_idx: Tensor | None, idx_s: Tensor, idx_t: Tensor, edge_vec_st: Tensor,
                 pos: Tensor, n_graphs: int | None = None):
         prop = run_mlp(self.out_lin, x)
@@ -571,8 +571,13 @@ class LCAONet(BaseMPNN):
             return forward_differentiable(self, graph)
         if precision not in ("fp32", "bf16x3"):
             raise ValueError(f"precision={precision!r}: expected 'fp32' or 'bf16x3'")
-        return self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision,
-                                       edge_context)
+        dev = graph[GraphKeys.Pos].device
+        if dev.type == "cuda":
+            ops.raise_pending_errors(dev)            # an earlier forward that has finished and flagged a bad index
+        out = self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision,
+                                      edge_context)
+        ops.publish_errors(dev)                      # this forward's flag: asynchronous copy, read when it has landed
+        return out
 
     @torch.no_grad()
     def pair_valence_mask(self, zdim: int) -> Tensor:
@@ -617,11 +622,12 @@ class LCAONet(BaseMPNN):
 
             return forward_with_autograd_forces(self, graph, ctx=edge_context)
         batch_idx = graph.get(GraphKeys.Batch_idx)
-        z = graph[GraphKeys.Z]
         pos = graph[GraphKeys.Pos]
         edge_index = graph[GraphKeys.Edge_idx]
         idx_s, idx_t = edge_index[0], edge_index[1]
         ops._dev(pos, "graph.pos")
+        # atomic numbers range-checked and clamped on the device (embed.py:41 indexes z - 1; the reference raises)
+        z = ops.checked_index(graph[GraphKeys.Z], 1, self.emb_layer.max_z, ops.FLAG_ATOMIC_NUMBER)
         N = z.size(0)
 
         # edge_context: the index structures of this edge list built earlier (EdgeContext.build) — they do not depend on

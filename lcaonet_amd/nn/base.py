@@ -62,7 +62,40 @@ class Dense(nn.Linear):
             self.weight_init.__name__ if self.weight_init is not None else None)
 
     def forward(self, x: Tensor, act: int = ops.ACT_NONE, residual: Tensor | None = None) -> Tensor:
+        """act(x W^T + b) + residual on the HIP dense kernel.  When autograd is on and the input or a parameter requires
+        grad, the layer runs as a twice-differentiable autograd Function over the same kernel (model/double.py: backward =
+        lcao_dense on W^T + lcao_wgrad), so composing Dense layers trains exactly as nn.Linear does."""
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad
+                                        or (self.bias is not None and self.bias.requires_grad)):
+            from ..model.double import dense as dense_fn
+
+            y = dense_fn(x, self.weight, self.bias)
+            if act == ops.ACT_SILU:
+                y = torch.nn.functional.silu(y)
+            elif act == ops.ACT_SIGMOID:
+                y = torch.sigmoid(y)
+            return y if residual is None else y + residual
         return ops.dense(x, self.weight.detach(), None if self.bias is None else self.bias.detach(), act, residual)
+
+
+def inference_only(fn):
+    """Decorator for module forwards that run the HIP inference kernels and record NO autograd graph (the operator-level
+    LCAOInteraction.forward / LCAOOut.forward).  The reference's versions are differentiable; rather than hand back a
+    tensor whose gradients silently miss these parameters, the call refuses when autograd is on and a parameter of the
+    module requires grad.  Under torch.no_grad() or with frozen parameters it runs as usual."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError(
+                f"{type(self).__name__}.{fn.__name__} runs the HIP inference kernels and records no autograd graph: call "
+                "it under torch.no_grad() (or freeze the parameters), or go through LCAONet.forward, which is "
+                "differentiable whenever autograd is on")
+        with torch.no_grad():
+            return fn(self, *args, **kwargs)
+
+    return wrapper
 
 
 def run_mlp(seq: nn.Sequential, x: Tensor) -> Tensor:

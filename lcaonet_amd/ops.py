@@ -93,11 +93,75 @@ def _call(name: str, *args) -> None:
     _PROFILE.setdefault(name, []).append((a, b))
 
 
+# --- sync-free index validation ----------------------------------------------------------------------------------
+# The kernels index tables by atomic number and node id; the reference raises IndexError for a bad one.  Here the first
+# kernel that touches an index range-checks it, CLAMPS it (no later kernel can read out of bounds) and sets a bit in a
+# device flag.  The flag travels to pinned host memory with an asynchronous copy at the end of a forward and is turned
+# into an exception as soon as that copy has landed (next forward, or ops.raise_pending_errors(sync=True)).
+FLAG_EDGE_INDEX, FLAG_ATOMIC_NUMBER = 1, 2
+_FLAG_TEXT = {FLAG_EDGE_INDEX: "edge_index holds a node id outside [0, N)",
+              FLAG_ATOMIC_NUMBER: "z holds an atomic number outside [1, max_z]"}
+
+
+class _ErrState:
+    def __init__(self, dev):
+        self.flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.pending = False
+
+
+_ERR: dict = {}
+
+
+def _err_state(dev) -> _ErrState:
+    key = torch.device(dev).index or 0
+    if key not in _ERR:
+        _ERR[key] = _ErrState(dev)
+    return _ERR[key]
+
+
+def publish_errors(dev) -> None:
+    """Enqueue the device flag's copy to the host (no synchronisation)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    st = _err_state(dev)
+    st.host.copy_(st.flag, non_blocking=True)
+    st.event.record()
+    st.pending = True
+
+
+def raise_pending_errors(dev=None, sync: bool = False) -> None:
+    """Raise LcaoHipError if a forward that has FINISHED flagged an invalid index (sync=True: wait for the last one)."""
+    for st in ([_err_state(dev)] if dev is not None else list(_ERR.values())):
+        if not st.pending or not (sync or st.event.query()):
+            continue
+        if sync:
+            st.event.synchronize()
+        code, st.pending = int(st.host[0]), False
+        if code:
+            st.flag.zero_()
+            st.host.zero_()
+            what = "; ".join(t for b, t in _FLAG_TEXT.items() if code & b)
+            raise _lib.LcaoHipError(f"invalid index in an earlier forward: {what} (the offending values were clamped on "
+                                    "the device, so that call's result is meaningless)")
+
+
+def checked_index(v: Tensor, lo: int, hi: int, bit: int) -> Tensor:
+    """v clamped to [lo, hi] (int64); values outside set `bit` of the device error flag."""
+    v = _i64(v, "index")
+    out = torch.empty_like(v)
+    _call("lcao_checked_index", _p(v), v.numel(), lo, hi, bit, _p(out), _p(_err_state(v.device).flag), _stream())
+    return out
+
+
+_ALLOW_CSR_CAPTURE = False   # tools/probe_csr_capture.py flips it; see profiles/r02/csr_capture_probe.txt for what it found
+
+
 def build_csr(idx_s: Tensor, idx_t: Tensor, n_nodes: int) -> dict:
     """All int32 index structures of one forward in one C-ABI call (no host sync, no torch sort)."""
-    if torch.cuda.is_current_stream_capturing():
-        # rocPRIM's device radix sort keeps host-side state per call; frozen into a HIP graph it faulted on replay
-        raise _lib.LcaoHipError("lcao_build_csr cannot be captured into a HIP graph: build the EdgeContext before the "
+    if torch.cuda.is_current_stream_capturing() and not _ALLOW_CSR_CAPTURE:
+        raise _lib.LcaoHipError("lcao_build_csr is not captured into HIP graphs: build the EdgeContext before the "
                                 "capture and pass it as edge_context= (lcaonet_amd.model.CapturedForward does)")
     idx_s, idx_t = _i64(idx_s, "edge_index[0]"), _i64(idx_t, "edge_index[1]")
     E, dev = idx_s.numel(), idx_s.device
@@ -109,7 +173,7 @@ def build_csr(idx_s: Tensor, idx_t: Tensor, n_nodes: int) -> dict:
     ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     _call("lcao_build_csr", _p(idx_s), _p(idx_t), E, n_nodes, _p(out["order"]), _p(out["src_p"]), _p(out["dst_p"]),
           _p(out["out_ptr"]), _p(out["in_ptr"]), _p(out["in_pos"]), _p(out["src_o"]), _p(out["dst_o"]), _p(ws), ws_bytes,
-          _stream())
+          _p(_err_state(dev).flag), _stream())
     return out
 
 

@@ -262,11 +262,17 @@ def test_operator_level_interaction_vs_oracle(dev):
         cfg = O.OracleConfig(emb_size=H, emb_size_coeff=C, emb_size_conv=V, add_valence=valence)
         want = O.interaction(sd, "L.", cfg, x, cst, vm, rb, shb, idx_s, idx_t, tri_k, e_ks, e_st)
         d = lambda t: None if t is None else t.to(dev)
-        got = layer.to(dev)(d(x), d(cst), d(vm), d(rb), d(shb), d(idx_s), d(idx_t), d(tri_k), d(e_ks), d(e_st))
-        assert relerr(got, want) <= TOL
-        if valence:
-            with pytest.raises(ValueError):
-                layer(d(x), d(cst), None, d(rb), d(shb), d(idx_s), d(idx_t), d(tri_k), d(e_ks), d(e_st))
+        layer = layer.to(dev)
+        args = (d(x), d(cst), d(vm), d(rb), d(shb), d(idx_s), d(idx_t), d(tri_k), d(e_ks), d(e_st))
+        with pytest.raises(RuntimeError, match="no autograd graph"):     # autograd on + trainable parameters: refuse loudly
+            layer(*args)
+        with torch.no_grad():
+            got = layer(*args)
+            assert relerr(got, want) <= TOL
+            if valence:
+                with pytest.raises(ValueError):
+                    layer(d(x), d(cst), None, d(rb), d(shb), d(idx_s), d(idx_t), d(tri_k), d(e_ks), d(e_st))
+        assert relerr(layer.requires_grad_(False)(*args), want) <= TOL       # frozen parameters: also fine
 
 
 def test_cfg1_full_size_vs_oracle(dev):
@@ -901,13 +907,49 @@ def test_error_behaviour(dev):
         ops.dense(x.cpu(), w.cpu())
     with pytest.raises(ValueError):
         ops.dense(x, torch.zeros(48, 32, device=dev))
-    layer = LCAOInteraction(16, 16, 16, add_valence=True).to(dev)
+    layer = LCAOInteraction(16, 16, 16, add_valence=True).to(dev).requires_grad_(False)
     e = torch.zeros(4, dtype=torch.long, device=dev)
     with pytest.raises(ValueError, match="valence_mask"):
         layer(torch.zeros(3, 16, device=dev), torch.zeros(4, 2, 16, device=dev), None, torch.zeros(4, 2, device=dev),
               torch.zeros(0, 2, device=dev), e, e, e[:0], e[:0], e[:0])
     for code in (0, -1, -2, -99, 1):
         assert _lib.load().lcao_error_string(code).decode()    # every code has a message (> 0: hipGetErrorString)
+    # indices the reference would answer with an IndexError: flagged on the device, clamped (nothing reads out of bounds),
+    # raised once the forward has finished — here by asking for it, in a serving loop at the next forward
+    from lcaonet_amd.data.graph import Data
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    m, _ = _random_model(dev, 1, emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=1, cutoff=4.0, max_z=10)
+    good = random_periodic_cells(2, 8, 6.0, 0.99 * 4.0, seed=2, max_z=10).to(dev)
+    ops.raise_pending_errors(sync=True)
+    m(good)
+    ops.raise_pending_errors(sync=True)                        # a valid graph raises nothing
+    bad_z = Data(**{**good.to_dict(), "z": good["z"].clone()})
+    bad_z["z"][3] = 11                                         # max_z = 10
+    out = m(bad_z)
+    assert bool(torch.isfinite(out).all())
+    with pytest.raises(_lib.LcaoHipError, match="atomic number"):
+        ops.raise_pending_errors(sync=True)
+    bad_e = Data(**{**good.to_dict(), "edge_index": good["edge_index"].clone()})
+    bad_e["edge_index"][1, 5] = good["z"].numel() + 7
+    m(bad_e)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.LcaoHipError, match="edge_index"):
+        m(good)                                                # the next forward reports it
+    ops.raise_pending_errors(sync=True)
+    # Dense composes like nn.Linear when gradients are wanted (HIP forward, HIP backward)
+    from lcaonet_amd.nn.base import Dense
+    lin = Dense(32, 48).to(dev)
+    lin.bias.data.normal_()
+    xin = torch.randn(20, 32, device=dev, requires_grad=True)
+    y = lin(xin, act=ops.ACT_SILU)
+    ref = torch.nn.functional.silu(torch.nn.functional.linear(xin.detach().double().requires_grad_(True), lin.weight.double(), lin.bias.double()))
+    assert y.requires_grad and relerr(y.detach(), ref.detach()) <= 2e-6
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = xin.detach().double().requires_grad_(True)
+    wr, br = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    torch.nn.functional.silu(torch.nn.functional.linear(xr, wr, br)).backward(gy.double())
+    assert relerr(xin.grad, xr.grad) <= 5e-6 and relerr(lin.weight.grad, wr.grad) <= 5e-6 and relerr(lin.bias.grad, br.grad) <= 5e-6
 
 
 def test_segment_sum_kernels(dev):
