@@ -248,6 +248,14 @@ int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, co
                            const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
                            float* msg, void* stream);
 
+/* The same with the node scatter of lcaonet.py:207-213 fused in: agg[s,:] = sum over the out-edges p of s of the message
+ * rows (edges sorted by centre; out_ptr from lcao_build_csr; a wave owns whole centre nodes, DPP segmented sums, no
+ * atomics, bitwise reproducible).  msg (E, V) is never written.  agg (n_nodes, V) is fully written (zero for nodes without
+ * edges).  n_edges = out_ptr[n_nodes]. */
+int lcao_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                               const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                               int64_t n_nodes, int64_t n_edges, int V, float* agg, void* stream);
+
 /* The same two kernels for a forward pass that will be differentiated (autograd forces, training): they also keep
  * ft = tbw W3^T (E,V) and pre2 = SiLU(Ps[s]+Pt[t]) Wn2^T + bn2 (E,V), the two intermediates the reverse sweep needs. */
 int lcao_edge_lcao_weight_saving(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges,

@@ -629,6 +629,178 @@ __global__ __launch_bounds__(256) void k_edge_node_message(const float* __restri
   }
 }
 
+// ===================================================================================================
+// lcao_edge_node_message_agg — lcao_edge_node_message with the node scatter of lcaonet.py:207-213 fused in:
+//   agg[s, :] = sum_{p in Out(s)} bw[p, :] * SiLU(Wn2 . SiLU(Ps[s] + Pt[dst(p)]) + bn2)
+// Edges are sorted by centre, so a wave takes CHUNKS OF WHOLE CENTRE NODES (`chunk_nodes` consecutive nodes, ~10 tiles of
+// 16 edges; only a chunk's last tile is partly empty) and walks their edges tile by tile.  After the GEMM a lane (r, q)
+// holds 32 message features of edge r; the rows of one node are summed across r with a masked 16-lane DPP reduction
+// (a tile spans 1-3 nodes), a node that continues into the next tile is carried in registers, and a finished node row is
+// stored once.  msg (E, V) — 1 KB per edge and layer — and the lcao_segment_sum launch disappear.  Fixed order (tile by
+// tile, fixed DPP tree): bitwise reproducible; no atomics.  `agg` must be zero-filled by the launcher (edgeless nodes).
+// ===================================================================================================
+template <int V>
+__global__ __launch_bounds__(256) void k_edge_node_message_agg(
+    const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
+    const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr,
+    const float* __restrict__ Wn2, const float* __restrict__ bn2, int n_nodes, int chunk_nodes, float* __restrict__ agg) {
+  constexpr int MT = V / 16;
+  extern __shared__ float lds[];
+  stage_weights(lds, Wn2, V, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int n_chunks = (n_nodes + chunk_nodes - 1) / chunk_nodes;
+  const int cstride = gridDim.x * 4;
+  // first non-empty chunk at or after c (wave-uniform): edges [b, e)
+  auto seek = [&](int& c, int& b, int& e) -> bool {
+    while (c < n_chunks) {
+      b = out_ptr[c * chunk_nodes];
+      e = out_ptr[min((c + 1) * chunk_nodes, n_nodes)];
+      if (e > b) return true;
+      c += cstride;
+    }
+    return false;
+  };
+  int chunk = blockIdx.x * 4 + wave, pb = 0, pend = 0;
+  bool have = seek(chunk, pb, pend);
+  f32x4v h[MT], carry[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) carry[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  int s_cur = 0;
+  int nchunk = chunk, npb = 0, npend = 0;
+  bool nhave = false;
+  int s_nxt = 0, d_nxt = 0;
+  if (have) {
+    const int pc = min(pb + r, pend - 1);
+    s_cur = src_p[pc];
+    const float* ps = Ps + (int64_t)s_cur * V + 4 * q;
+    const float* pt = Pt + (int64_t)dst_p[pc] * V + 4 * q;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      f32x4v sv = *(const f32x4v*)(ps + 16 * a) + *(const f32x4v*)(pt + 16 * a);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[a][j] = lcao_silu(sv[j]);
+    }
+    npb = pb + 16; npend = pend; nhave = true;
+    if (npb >= pend) { nchunk = chunk + cstride; nhave = seek(nchunk, npb, npend); }
+    if (nhave) {
+      const int pn = min(npb + r, npend - 1);
+      s_nxt = src_p[pn];
+      d_nxt = dst_p[pn];
+    }
+  }
+  while (have) {
+    asm volatile("" ::: "memory");
+    const bool valid = pb + r < pend;
+    const int64_t pw = min(pb + r, pend - 1);
+    // node rows of the next tile: requested now, consumed after this tile's GEMM
+    f32x4v ns[MT], nt[MT];
+    int n2chunk = nchunk, n2pb = 0, n2pend = 0;
+    bool n2have = false;
+    int s_n2 = 0, d_n2 = 0;
+    if (nhave) {
+      const float* ps = Ps + (int64_t)s_nxt * V + 4 * q;
+      const float* pt = Pt + (int64_t)d_nxt * V + 4 * q;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) ns[a] = *(const f32x4v*)(ps + 16 * a);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) nt[a] = *(const f32x4v*)(pt + 16 * a);
+      n2pb = npb + 16; n2pend = npend; n2have = true;
+      if (n2pb >= npend) { n2chunk = nchunk + cstride; n2have = seek(n2chunk, n2pb, n2pend); }
+      if (n2have) {
+        const int pn2 = min(n2pb + r, n2pend - 1);
+        s_n2 = src_p[pn2];
+        d_n2 = dst_p[pn2];
+      }
+    }
+    f32x4v o[MT], wv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wv[m] = *(const f32x4v*)(bw + pw * V + 16 * m + 4 * q);  // in flight under the GEMM
+#pragma unroll
+    for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
+    __builtin_amdgcn_s_setprio(1);
+    mfma_layer<MT, MT>(lds, V + 4, r, q, h, o);
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[m][j] = valid ? wv[m][j] * lcao_silu(o[m][j]) : 0.f;   // message rows; 0 past the chunk
+    // segmented sum over the 16 edges of the tile, node by node (wave-uniform loop; 1-3 nodes per tile)
+    const int s_first = __builtin_amdgcn_readfirstlane(s_cur);
+    const int s_last = __builtin_amdgcn_readlane(s_cur, min(15, pend - pb - 1));
+    for (int node = s_first; node <= s_last; ++node) {
+      const int e_beg = out_ptr[node], e_end = out_ptr[node + 1];
+      if (e_end == e_beg) continue;
+      const bool mine = s_cur == node;          // (invalid lanes hold zeros already)
+      const bool fresh = e_beg >= pb;           // the node's first edge lies in this tile: no carry to add
+      const bool done = e_end <= pb + 16;       // ... and its last one too: the row is complete
+      float* out = agg + (int64_t)node * V + 4 * q;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        f32x4v t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = lcao_row16_sum(mine ? o[m][j] : 0.f);
+        if (!fresh) t += carry[m];
+        if (done) {
+          if (r == 0) *(f32x4v*)(out + 16 * m) = t;
+        } else {
+          carry[m] = t;
+        }
+      }
+    }
+    // rotate the pipeline
+    if (nhave) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        f32x4v sv = ns[a] + nt[a];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[a][j] = lcao_silu(sv[j]);
+      }
+    }
+    have = nhave; chunk = nchunk; pb = npb; pend = npend; s_cur = s_nxt;
+    nhave = n2have; nchunk = n2chunk; npb = n2pb; npend = n2pend; s_nxt = s_n2; d_nxt = d_n2;
+  }
+}
+
+extern "C" int lcao_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                          const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                                          int64_t n_nodes, int64_t n_edges, int V, float* agg, void* stream) {
+  LCAO_CHECK_SIZE(n_nodes);
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0) return LCAO_ERR_INVALID;
+  if (n_nodes == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(agg);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t me = hipMemsetAsync(agg, 0, sizeof(float) * (size_t)n_nodes * V, st);   // nodes without edges stay zero
+  if (me != hipSuccess) return int(me);
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p);
+  LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(Wn2); LCAO_CHECK_PTR(bn2);
+  // ~10 tiles of 16 edges per chunk of whole nodes: the one partly empty tile per chunk costs ~5 % of the matrix work
+  int64_t chunk_nodes = (160 * n_nodes + n_edges - 1) / n_edges;
+  if (chunk_nodes < 1) chunk_nodes = 1;
+  if (chunk_nodes > 64) chunk_nodes = 64;
+  const int64_t n_chunks = (n_nodes + chunk_nodes - 1) / chunk_nodes;
+  size_t lds = size_t(V) * (V + 4) * sizeof(float);
+  int64_t per_cu = (lds > 80 * 1024) ? 1 : ((lds > 53 * 1024) ? 2 : 3);
+  int64_t groups = (n_chunks + 3) / 4, cap = (int64_t)lcao_num_cu() * per_cu;
+  if (groups > cap) groups = cap;
+#define NMA_CASE(V_)                                                                                             \
+  if (V == V_) {                                                                                                 \
+    static bool done = false;                                                                                    \
+    int rc = set_lds_attr(k_edge_node_message_agg<V_>, lds, done);                                               \
+    if (rc != LCAO_OK) return rc;                                                                                \
+    hipLaunchKernelGGL(k_edge_node_message_agg<V_>, dim3((unsigned)groups), dim3(256), lds, st, bw, Ps, Pt, src_p,   \
+                       dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)chunk_nodes, agg);                           \
+    return lcao_launch_status();                                                                                 \
+  }
+  NMA_CASE(128) NMA_CASE(64) NMA_CASE(32)
+#undef NMA_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}
+
 static int launch_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges,
                                    int V, float* bw, float* ft_out, void* stream) {
   LCAO_CHECK_SIZE(n_edges);

@@ -133,6 +133,8 @@ def publish_errors(dev) -> None:
 
 def raise_pending_errors(dev=None, sync: bool = False) -> None:
     """Raise LcaoHipError if a forward that has FINISHED flagged an invalid index (sync=True: wait for the last one)."""
+    if torch.cuda.is_current_stream_capturing():     # event queries are not allowed while a HIP graph is being captured
+        return
     for st in ([_err_state(dev)] if dev is not None else list(_ERR.values())):
         if not st.pending or not (sync or st.event.query()):
             continue
@@ -519,6 +521,18 @@ def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, precision="fp32", save
     _call("lcao_edge_node_message_bf16x3" if precision == "bf16x3" else "lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg),
                                           _stream())
     return msg
+
+
+def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2):
+    """agg (n_centres, V): edge_node_message + the per-centre segment sum in one kernel (msg is never materialised).
+    out_ptr (n_centres + 1) int32; the first out_ptr[-1] rows of bw / src_p / dst_p are the centres' out-edges."""
+    bw, Ps, Pt, Wn2, bn2 = _f32(bw), _f32(Ps), _f32(Pt), _f32(Wn2), _f32(bn2)
+    E, V = bw.shape
+    n = out_ptr.numel() - 1
+    agg = torch.empty(n, V, device=bw.device, dtype=torch.float32)
+    _call("lcao_edge_node_message_agg", _p(bw), _p(Ps), _p(Pt), _p(_i32(src_p)), _p(_i32(dst_p)), _p(_i32(out_ptr)), _p(Wn2),
+          _p(bn2), n, E, V, _p(agg), _stream())
+    return agg
 
 
 # --- activation-gradient kernels (autograd forces at inference; csrc/lcao_backward.hip) -------------------------
