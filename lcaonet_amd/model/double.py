@@ -144,7 +144,10 @@ def scatter_sum(rows: Tensor, plan: IndexPlan) -> Tensor:
 class _Geo:
     """Static index structures of one graph, everything in p-space (edges sorted by centre)."""
 
-    def __init__(self, model, graph):
+    def __init__(self, model, graph, n_own: int | None = None, e_own: int | None = None):
+        """n_own / e_own (one rank of a sharded graph, lcaonet_amd/shard.py): only the first n_own nodes are centres and
+        only the first e_own edges of p-space carry messages and triplets; every local edge still gets geometry, radial
+        basis and coefficient rows (ghost-centred in-edges feed the three-body term)."""
         from .lcaonet import EdgeContext
 
         z = graph[GraphKeys.Z]
@@ -152,10 +155,16 @@ class _Geo:
         self.z, self.N = z, z.numel()
         ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], self.N)
         self.ctx, self.E = ctx, ctx.n_edges
+        self.n_own = self.N if n_own is None else n_own
+        self.e_own = self.E if e_own is None else e_own
         self.l_of_d, self.n_l = model.shbf.l_of_d, model.n_l
         self.zdim = model.emb_layer.max_z + 1
         order = ctx.order.long()
         self.src, self.dst = IndexPlan(ctx.src_p, self.N, is_sorted=True), IndexPlan(ctx.dst_p, self.N)
+        # the owned out-edges: gathers from (N, .) node tables, scatter into the n_own centre rows
+        self.src_o = IndexPlan(ctx.src_p[: self.e_own], self.N, is_sorted=True)
+        self.dst_o = IndexPlan(ctx.dst_p[: self.e_own], self.N)
+        self.agg = IndexPlan(ctx.src_p[: self.e_own], self.n_own, is_sorted=True)
         self.zplan = IndexPlan(z, self.zdim)
         batch = graph.get(GraphKeys.Batch_idx)
         shift = graph[GraphKeys.Edge_shift][order].float()
@@ -170,6 +179,7 @@ class _Geo:
         m_in = (ctx.in_ptr[1:] - ctx.in_ptr[:-1]).long()
         m_out = (ctx.out_ptr[1:] - ctx.out_ptr[:-1]).long()
         prod = m_in * m_out
+        prod[self.n_own:] = 0                                        # ghost nodes are not centres here
         self.tbase = (torch.cumsum(prod, 0) - prod).contiguous()
         T = int(prod.sum().item())                                   # host sync: this mode sizes T-long scalar tensors
         self.T = T
@@ -348,11 +358,18 @@ def _triplet_weights(geo: _Geo, u: Tensor, G: Tensor) -> Tensor:
     return y * inv.unsqueeze(1) * geo.tmask
 
 
-def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_direct_forces: bool = False):
+def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_direct_forces: bool = False, shard=None):
     """(B, out_size) model output as a twice-differentiable function of pos (N, 3) and of every parameter.
     x_tab (zdim, H) / cst_pair (zdim^2, D, C): the species tables (model/train.py::species_tables_autograd).
-    with_direct_forces: also return the direct-force head's (N, 3) output (lcaonet.py:303-308)."""
-    geo = _Geo(model, graph)
+    with_direct_forces: also return the direct-force head's (N, 3) output (lcaonet.py:303-308).
+    shard = (plan, exchange(x_own) -> ghost rows, reduce(partial) -> global sums), both autograd-aware
+    (lcaonet_amd/shard.py): this rank's part of a graph partitioned by centre node; returns the GLOBAL (B, out)."""
+    if shard is not None:
+        plan = shard[0]
+        geo = _Geo(model, graph, plan.n_own, plan.e_own)
+    else:
+        geo = _Geo(model, graph)
+    n_own = geo.n_own
     V = model.emb_size_conv
     vec = gather(pos, geo.dst) - gather(pos, geo.src) + geo.cell_shift
     dist = vec.norm(dim=1)
@@ -360,7 +377,9 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
     rb = model.rbf.differentiable(dist)                                       # (E, D), p-space
     x = gather(x_tab, geo.zplan)                                              # (N, H)
     mask_pair = model.pair_valence_mask(geo.zdim).unsqueeze(-1) if model.add_valence else None
-    for layer in model.int_layers:
+    for li, layer in enumerate(model.int_layers):
+        if shard is not None and li > 0 and plan.n_ghost:
+            x = torch.cat([x, shard[1](x)], dim=0)                            # halo rows of the previous layer's output
         nw = dense(x, layer.node_weight.weight, layer.node_weight.bias)
         xs, xk = nw[:, :V], nw[:, V:]
         gate = torch.sigmoid(xk)
@@ -377,19 +396,29 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
             B, Bv = A.sum(dim=1), None
         Ag = A * gather(gate, geo.src).unsqueeze(1)
         G = torch.einsum("elv,emv->elm", A, A)
-        tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)
+        tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)               # (e_own, V)
         ft = dense(tbw, layer.f_three[0].weight)
+        B = B[: geo.e_own]
         if Bv is None:
             lw_in = B + B * ft
         else:
+            Bv = Bv[: geo.e_own]
             lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
         bw = dense(F.normalize(lw_in, dim=-1), layer.basis_weight.weight)
-        h1 = layer.f_node[1](gather(Ps, geo.src) + gather(Pt, geo.dst))
+        h1 = layer.f_node[1](gather(Ps, geo.src_o) + gather(Pt, geo.dst_o))
         h2 = layer.f_node[3](dense(h1, layer.f_node[2].weight, layer.f_node[2].bias))
-        x = x + dense(scatter_sum(bw * h2, geo.src), layer.out_weight.weight)
+        x = x[:n_own] + dense(scatter_sum(bw * h2, geo.agg), layer.out_weight.weight)
     prop = _mlp(model.out_layer.out_lin, x)
     batch = graph.get(GraphKeys.Batch_idx)
     ext = model.out_layer.is_extensive
+    if shard is not None:
+        from .sharded import finish_outputs
+
+        bplan = IndexPlan(batch[:n_own], plan.n_graphs)
+        parts = [scatter_sum(prop, bplan), (bplan.ptr[1:] - bplan.ptr[:-1]).to(prop.dtype).unsqueeze(1)]
+        if model.pp_layer.atomref is not None:
+            parts.append(scatter_sum(model.pp_layer.atomref[geo.z[:n_own]].float().contiguous(), bplan))
+        return finish_outputs(model, shard[2](torch.cat(parts, dim=1)))
     if batch is not None:
         from .base import num_graphs
 
@@ -403,8 +432,8 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
     out = model.pp_layer(out, geo.z, batch, out.shape[0])
     if not with_direct_forces:
         return out
-    f = _mlp(model.out_layer.out_lin_force, torch.cat([gather(x, geo.src), gather(x, geo.dst)], dim=-1)) * u
-    return out, scatter_sum(f, geo.src)
+    f = _mlp(model.out_layer.out_lin_force, torch.cat([gather(x, geo.src_o), gather(x, geo.dst_o)], dim=-1)) * u
+    return out, scatter_sum(f, geo.agg)
 
 
 def forward_exact_forces(model, graph, update_stats: bool = True, tables=None):
@@ -438,3 +467,33 @@ def forward_generic(model, graph, update_stats: bool = True):
         return forward_exact_forces(model, graph, update_stats, tables=(x_tab, cst_pair))
     pos = graph[GraphKeys.Pos].detach().float()
     return energy(model, graph, pos, x_tab, cst_pair, with_direct_forces=model.regress_forces)
+
+
+def forward_sharded_differentiable(model, plan, group=None, update_stats: bool = True, exchange=None, reduce=None,
+                                   count_reduce=None):
+    """LCAONet.forward on ONE graph partitioned over ranks (lcaonet_amd/shard.py) WITH an autograd graph — single-graph
+    training.  Returns the global (B, out) result, identical on every rank.  What crosses ranks:
+      * forward: the L-1 halo exchanges and the all-reduce of the per-graph partial sums; backward: the same exchanges run
+        backwards (dE/dx of ghost rows returns to the owners) — shard.halo_exchange / shard.all_reduce_sum are autograd
+        Functions whose backward is the adjoint collective;
+      * BatchNorm batch statistics: count-weighted statistics over species / species pairs, so ONE all-reduce of the
+        (zdim + zdim^2) histogram of owned atoms / owned edges gives every rank the statistics of the whole graph;
+      * afterwards the caller sums the parameter gradients over the ranks (shard.all_reduce_gradients): each rank holds
+        the part of dL/dtheta that flows through ITS atoms and edges.
+    Energies only (regress_forces models raise)."""
+    from .. import shard as sh
+    from .train import species_tables_autograd
+
+    if model.regress_forces:
+        raise NotImplementedError("sharded training: energies only")
+    g = plan.graph
+    z = g[GraphKeys.Z]
+    idx_s, idx_t = g[GraphKeys.Edge_idx]
+    own_e = idx_s < plan.n_own
+    exchange = exchange or (lambda x_own: sh.halo_exchange(x_own, plan, group))
+    reduce = reduce or (lambda part: sh.all_reduce_sum(part, group))
+    count_reduce = count_reduce or (lambda c: sh.reduce_graph_outputs(c, group))
+    x_tab, cst_pair, _, _ = species_tables_autograd(model, z, idx_s[own_e], idx_t[own_e], update_stats,
+                                                    count_reduce=count_reduce, n_own=plan.n_own)
+    pos = g[GraphKeys.Pos].detach().float()
+    return energy(model, g, pos, x_tab, cst_pair, shard=(plan, exchange, reduce))

@@ -518,8 +518,10 @@ class LCAONet(BaseMPNN):
         from .. import shard
         from .sharded import ShardedForward
 
+        # NOTE: this decorated method is the graph-less path; LCAONet.forward_sharded_train carries the autograd graph
         if self.training:
-            raise NotImplementedError("forward_sharded: eval mode only (BatchNorm batch statistics would need a collective)")
+            raise NotImplementedError("forward_sharded is the inference path (eval mode); single-graph training: "
+                                      "forward_sharded_train(plan, group)")
         if self.regress_forces and not self.direct_forces:
             # F = -dE/dpos of the owned atoms: sharded reverse sweep with L reverse halo exchanges (model/forces.py)
             from .forces import run_sharded_forces
@@ -542,6 +544,15 @@ class LCAONet(BaseMPNN):
             ghosts = exchange_fn(x_own) if exchange_fn is not None else shard.exchange_ghosts(plan, x_own, group)
             return out, sf.direct_forces(ghosts)
         return out
+
+    def forward_sharded_train(self, plan, group=None, **kw):
+        """This rank's part of a DIFFERENTIABLE forward on one graph partitioned by centre node: returns the global
+        (B, out) result with an autograd graph (train or eval mode; BatchNorm batch statistics of the whole graph through
+        one all-reduce of species / pair counts).  After loss.backward() call shard.all_reduce_gradients(model, group).
+        See model/double.py::forward_sharded_differentiable."""
+        from .double import forward_sharded_differentiable
+
+        return forward_sharded_differentiable(self, plan, group, **kw)
 
     # --- forward ------------------------------------------------------------------------------------------
     def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,

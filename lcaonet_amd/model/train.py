@@ -56,9 +56,13 @@ def _bn_weighted(bn: nn.BatchNorm1d, h: Tensor, w: Tensor, n_samples: int, train
     return (h - mean) / torch.sqrt(var + bn.eps) * bn.weight + bn.bias
 
 
-def species_tables_autograd(model, z: Tensor, idx_s: Tensor, idx_t: Tensor, update_stats: bool = True):
+def species_tables_autograd(model, z: Tensor, idx_s: Tensor, idx_t: Tensor, update_stats: bool = True, count_reduce=None,
+                            n_own: int | None = None):
     """x_tab (max_z+1, H) and cst_pair ((max_z+1)^2, D, C), differentiable w.r.t. every embedding parameter.
-    update_stats=False: train-mode batch statistics without touching the BatchNorm running buffers (extra passes)."""
+    update_stats=False: train-mode batch statistics without touching the BatchNorm running buffers (extra passes).
+    count_reduce / n_own (one graph sharded over ranks): z holds this rank's local atoms (the first n_own are OWNED),
+    idx_s / idx_t its owned edges; count_reduce(counts) sums the species / pair histograms over the ranks — the BatchNorm batch statistics of the whole
+    graph are functions of those counts alone, so every rank gets the same tables (embed.py:175,232)."""
     emb = model.emb_layer
     dev = z.device
     Z = emb.max_z
@@ -73,10 +77,15 @@ def species_tables_autograd(model, z: Tensor, idx_s: Tensor, idx_t: Tensor, upda
     else:
         coeff_e, node_in = e_embed, node_z
     zd = Z + 1
-    N, E = z.numel(), idx_s.numel()
-    cnt_z = torch.zeros(zd, device=dev).scatter_add_(0, z, torch.ones(N, device=dev))
+    z_cnt = z if n_own is None else z[:n_own]
+    N, E = z_cnt.numel(), idx_s.numel()
+    cnt_z = torch.zeros(zd, device=dev).scatter_add_(0, z_cnt, torch.ones(N, device=dev))
     pair = z[idx_s] * zd + z[idx_t]
     cnt_p = torch.zeros(zd * zd, device=dev).scatter_add_(0, pair, torch.ones(E, device=dev))
+    if count_reduce is not None:
+        tot = count_reduce(torch.cat([cnt_z, cnt_p]))
+        cnt_z, cnt_p = tot[:zd], tot[zd:]
+        N, E = int(round(float(cnt_z.sum()))), int(round(float(cnt_p.sum())))
     # node table
     h = _mlp(emb.node_embed.f_enc, node_in)                                    # (Z, H)
     x_tab = _bn_weighted(emb.node_embed.bn, h, cnt_z[1:] / N, N, model.training, update_stats)

@@ -676,8 +676,8 @@ def geometry_bwd(dist, uvec, g_rb, g_u, orb_table, rbf_kind, cutoff_kind, rc):
 def trip_spmm(w, A, geo):
     """out[p,:] = sum_{q,l} w[t(p,q),l] A[q,l,:];  geo: model/double.py::_Geo (CSR + triplet slot bases)."""
     w, A = _f32(w, "w"), _f32(A, "A")
-    E, n_l, V = A.shape
-    c = geo.ctx
+    _, n_l, V = A.shape
+    c, E = geo.ctx, geo.e_own
     out = torch.empty(E, V, device=A.device, dtype=torch.float32)
     _call("lcao_trip_spmm", _p(w), _p(A), _p(c.src_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), E, V, n_l,
           _p(out), _stream())
@@ -687,20 +687,20 @@ def trip_spmm(w, A, geo):
 def trip_spmm_t(w, G, geo):
     """out[q,l,:] = sum_p w[t(p,q),l] G[p,:]"""
     w, G = _f32(w, "w"), _f32(G, "G")
-    E, V = G.shape
+    V = G.shape[1]
     n_l = w.shape[1]
-    c = geo.ctx
+    c, E = geo.ctx, geo.E
     out = torch.empty(E, n_l, V, device=G.device, dtype=torch.float32)
     _call("lcao_trip_spmm_t", _p(w), _p(G), _p(c.dst_p), _p(geo.in_rank), _p(c.in_ptr), _p(c.out_ptr), _p(geo.tbase), E,
-          c.n_nodes, V, n_l, _p(out), _stream())
+          geo.n_own, V, n_l, _p(out), _stream())
     return out
 
 
 def trip_sddmm(G, A, geo):
     """out[t,l] = G[p,:] . A[q,l,:]"""
     G, A = _f32(G, "G"), _f32(A, "A")
-    E, n_l, V = A.shape
-    c = geo.ctx
+    _, n_l, V = A.shape
+    c, E = geo.ctx, geo.e_own
     out = torch.zeros(geo.T, n_l, device=A.device, dtype=torch.float32)
     _call("lcao_trip_sddmm", _p(G), _p(A), _p(c.src_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), E, V, n_l,
           _p(out), _stream())

@@ -294,3 +294,66 @@ def reduce_graph_outputs(partial: Tensor, group=None) -> Tensor:
     out = partial.clone()
     dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
     return out
+
+
+# --- autograd-aware collectives (single-graph TRAINING, model/double.py::forward_sharded_differentiable) ----------
+class _HaloFn(torch.autograd.Function):
+    """ghost rows = exchange(x_own); backward: the exchange run backwards (what every rank holds for its ghosts returns
+    to the owners, summed per node).  The two are adjoint, so each one's backward is the other — any order of derivative."""
+
+    @staticmethod
+    def forward(ctx, x_own, plan, group):
+        ctx.plan, ctx.group = plan, group
+        return exchange_ghosts(plan, x_own.contiguous(), group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _HaloTFn.apply(g.contiguous(), ctx.plan, ctx.group), None, None
+
+
+class _HaloTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_ghost, plan, group):
+        ctx.plan, ctx.group = plan, group
+        return reverse_exchange(plan, g_ghost.contiguous(), group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _HaloFn.apply(g.contiguous(), ctx.plan, ctx.group), None, None
+
+
+def halo_exchange(x_own: Tensor, plan: ShardPlan, group=None) -> Tensor:
+    return _HaloFn.apply(x_own, plan, group)
+
+
+class _AllReduceSumFn(torch.autograd.Function):
+    """out = sum over ranks (identical everywhere).  The loss is then computed identically on every rank, so a rank's
+    backward takes dL/dout as it is: the gradient of ITS addend (summing the ranks' parameter gradients afterwards gives
+    the total)."""
+
+    @staticmethod
+    def forward(ctx, part, group):
+        return reduce_graph_outputs(part, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def all_reduce_sum(part: Tensor, group=None) -> Tensor:
+    return _AllReduceSumFn.apply(part, group)
+
+
+def all_reduce_gradients(model, group=None) -> None:
+    """Sum every parameter gradient over the ranks (after backward of a sharded differentiable forward)."""
+    import torch.distributed as dist
+
+    for p in model.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        if p.grad.is_cuda and dist.get_backend(group) == "gloo":     # CPU rehearsal of the RCCL path
+            g = p.grad.cpu()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+            p.grad.copy_(g)
+        else:
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group)

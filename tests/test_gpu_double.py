@@ -147,3 +147,67 @@ def test_trip_bilinear_family_is_consistent(dev):
         assert relerr(ops.trip_spmm_t(w, G, geo), want_t) <= 2e-6
         want_d = torch.einsum("tv,tlv->tl", G.double()[tp], A.double()[tq])
         assert relerr(ops.trip_sddmm(G, A, geo), want_d) <= 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# single-graph TRAINING over ranks (BatchNorm statistics of the whole graph, autograd-aware halo exchange)
+# ---------------------------------------------------------------------------------------------------------------------
+SH_KW = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=3, cutoff=4.0, out_size=2)
+
+
+def _sharded_train_worker(rank, world, port, training, ret):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lcaonet_amd import shard
+        from lcaonet_amd.data.synthetic import random_periodic_cells
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        m, _ = _random_model(dev, 4242, grad=True, **SH_KW)
+        m.train(training)
+        g = random_periodic_cells(1, 48, 9.0, 0.99 * 4.0, seed=23).to(dev)
+        plan = shard.make_plans(g, world)[rank]
+        out = m.forward_sharded_train(plan)
+        loss = ((out - 0.3) ** 2).sum()
+        loss.backward()
+        shard.all_reduce_gradients(m)
+        ret[rank] = (out.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters()},
+                     m.emb_layer.node_embed.bn.running_mean.detach().cpu(), plan.n_ghost)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_sharded_training_matches_single_process(dev, training):
+    """Two ranks (sharing cuda:0, talking over gloo) each hold half of ONE periodic cell: the global output, every
+    parameter gradient after shard.all_reduce_gradients and the BatchNorm running statistics equal the single-process
+    differentiable forward on the whole graph (train mode: batch statistics of the WHOLE graph from all-reduced counts)."""
+    import socket
+    import torch.multiprocessing as mp
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    m, _ = _random_model(dev, 4242, grad=True, **SH_KW)
+    m.train(training)
+    g = random_periodic_cells(1, 48, 9.0, 0.99 * 4.0, seed=23).to(dev)
+    want = m(g, differentiable=True)
+    ((want - 0.3) ** 2).sum().backward()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_sharded_train_worker, args=(2, port, training, ret), nprocs=2, join=True)
+    assert len(ret) == 2
+    for r in range(2):
+        out, grads, run_mean, n_ghost = ret[r]
+        assert n_ghost > 0
+        assert relerr(out, want.detach()) <= 1e-5
+        assert relerr(run_mean, m.emb_layer.node_embed.bn.running_mean) <= 1e-6
+        checked = 0
+        for n, p in m.named_parameters():
+            if p.grad is None or float(p.grad.abs().max()) < 1e-10:
+                continue
+            assert relerr(grads[n], p.grad) <= 2e-4, (n, relerr(grads[n], p.grad))
+            checked += 1
+        assert checked > 25
