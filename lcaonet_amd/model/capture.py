@@ -1,7 +1,7 @@
 """HIP-graph replay of a whole forward (energies, or energies + autograd forces) for a FIXED edge list.
 
 The inference pipeline has no host synchronisation (index structures come from lcao_build_csr, the tile queue is re-armed
-by a stream-ordered memset), so one `model(graph)` call — ~130 kernel launches — can be captured once and replayed with
+by a stream-ordered memset), so one `model(graph)` call can be captured once and replayed with
 new positions.  That is the molecular-dynamics inner loop between neighbour-list rebuilds: an edge list built with a skin
 stays valid while atoms move less than the skin, and edges that drift beyond the cutoff contribute exactly zero through the
 cutoff envelope (lcaonet/nn/cutoff.py), as they do in the reference when handed such a list.  For a 64-atom cell the
@@ -31,8 +31,8 @@ class CapturedForward:
         self.model = model
         self.kwargs = forward_kwargs
         self.static = Data(**{k: graph[k].clone() for k in _KEYS if graph.get(k) is not None})
-        # the CSR / ordering structures depend on the edge list only: built once, OUTSIDE the capture (their construction
-        # uses rocPRIM's device sort, whose host-side bookkeeping must not be frozen into a graph)
+        # the CSR / ordering structures depend on the edge list only: built once, outside the capture (lcao_build_csr is
+        # capturable — profiles/r02/csr_capture_probe.txt — but a capture has a fixed edge list anyway: 0.19 ms less per replay)
         from .lcaonet import EdgeContext
         self.edge_context = EdgeContext.build(self.static[GraphKeys.Edge_idx], self.static[GraphKeys.Z].numel())
         forward_kwargs = dict(forward_kwargs, edge_context=self.edge_context)

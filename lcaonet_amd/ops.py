@@ -157,14 +157,9 @@ def checked_index(v: Tensor, lo: int, hi: int, bit: int) -> Tensor:
     return out
 
 
-_ALLOW_CSR_CAPTURE = False   # tools/probe_csr_capture.py flips it; see profiles/r02/csr_capture_probe.txt for what it found
-
-
+# lcao_build_csr (two rocPRIM radix sorts + lower bounds) is capturable into a HIP graph: profiles/r02/csr_capture_probe.txt
 def build_csr(idx_s: Tensor, idx_t: Tensor, n_nodes: int) -> dict:
-    """All int32 index structures of one forward in one C-ABI call (no host sync, no torch sort)."""
-    if torch.cuda.is_current_stream_capturing() and not _ALLOW_CSR_CAPTURE:
-        raise _lib.LcaoHipError("lcao_build_csr is not captured into HIP graphs: build the EdgeContext before the "
-                                "capture and pass it as edge_context= (lcaonet_amd.model.CapturedForward does)")
+    """All int32 index structures of one forward in one C-ABI call (no host sync, no torch sort; capture-safe)."""
     idx_s, idx_t = _i64(idx_s, "edge_index[0]"), _i64(idx_t, "edge_index[1]")
     E, dev = idx_s.numel(), idx_s.device
     i32 = lambda n: torch.empty(n, device=dev, dtype=torch.int32)
