@@ -111,11 +111,23 @@ def cpu_baseline(max_seconds: float = 25.0) -> dict:
                       f"E={E}, median of 3 runs at the best of {candidates} torch CPU threads (host has {ncpu})"}
 
 
+PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
+
+
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json), or None."""
-    path = os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02/pmc_traffic.json: separate FETCH_SIZE /
+    WRITE_SIZE passes of this same workload, gfx950 x2 read correction), or None.  NOT measured in this run: the file
+    carries the commit and date of its passes, repeated in the line as `traffic_source`."""
     try:
-        return json.load(open(path))[kernel]["hbm_bytes_per_launch"]
+        return json.load(open(os.path.join(REPO, PMC_FILE)))[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def pmc_source():
+    try:
+        d = json.load(open(os.path.join(REPO, PMC_FILE)))
+        return f"{PMC_FILE} (PMC passes at commit {d.get('_commit')}, {d.get('_date')}; not re-measured in this run)"
     except Exception:
         return None
 
@@ -249,6 +261,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary modes (profiling runs)")
     ap.add_argument("--fused", type=int, default=-1, help="-1 auto, 0 generic kernels only, 1 force fused")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--n-side", type=int, default=0, help="cfg4: atoms per crystal edge (0 = 126 at 8 ranks, 250 k atoms per rank otherwise)")
@@ -361,7 +374,7 @@ def main():
     pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = mat_ms = mat_err = None
     secondary_error = None
     kall = {}
-    if rank == 0:
+    if rank == 0 and not args.no_secondary:
         try:
             with torch.no_grad(), ops.profile() as prof_all:                 # per-entry-point breakdown, separate pass
                 for _ in range(args.steps):
@@ -469,7 +482,7 @@ def main():
                                    "gathered from the (z_s, z_t) table inside the kernel instead of a materialised (E,D,C) tensor"
                                    + (" + forces = -dE/dpos (reverse sweep)" if with_forces else ""),
                        "edges_per_gpu": E, "nodes_per_gpu": N, "sharding": "whole crystals per rank, no collective"},
-            "roofline": roof, "roofline_hbm": roof_hbm,
+            "roofline": roof, "roofline_hbm": roof_hbm, "traffic_source": pmc_source(),
             "roofline_forward": roofline_forward(model, N, E, elapsed_max / args.steps),
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(kall.items(), key=lambda kv: -kv[1][1])},
             "kernel_ms_per_step_note": "separate pass after the timed region with every C-ABI call bracketed by HIP events",
