@@ -183,10 +183,25 @@ def run_case(name, graph_dict, kwargs, seed=0, train=False, keep_triplets=False,
 
 
 def graph_to_dict(g):
-    return {k: g[k] for k in g.keys()}
+    return {k: g[k] for k in g.keys() if torch.is_tensor(g[k])}
+
+
+def extra_cases():
+    """Round-2 additions (`python oracle/make_golden.py extra`): activations other than SiLU (lcaonet/nn/activation.py,
+    utils/resolve.py:66), which the round-1 fixtures do not cover.  Own seeds, so the earlier fixtures are untouched."""
+    fx = graph_to_dict(reference_fixture_graph())
+    small = dict(emb_size=16, emb_size_coeff=16, emb_size_conv=10, out_size=1, n_interaction=3, cutoff=6.0)
+    run_case("fixture_shiftedsoftplus", fx, {**small, "activation": "ShiftedSoftplus"}, seed=40, keep_triplets=True)
+    g1 = graph_to_dict(random_periodic_cells(2, 12, 6.0, 0.99 * 5.0, max_z=36, seed=7))
+    run_case("cells_h16_tanh_autograd_forces", g1,
+             dict(emb_size=16, emb_size_coeff=16, emb_size_conv=16, n_interaction=2, cutoff=5.0, activation="Tanh",
+                  regress_forces=True, direct_forces=False), 41)
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra_cases()
+        return
     tables()
     basis()
     fx = graph_to_dict(reference_fixture_graph())

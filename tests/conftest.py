@@ -69,6 +69,7 @@ MODEL_CASES = [
     "fixture_default", "fixture_valence", "fixture_valence_extend", "fixture_n_per_orb2", "fixture_max_orb4p",
     "fixture_bessel", "fixture_cosine_noelec_mean", "fixture_atomref", "fixture_dims", "fixture_direct_forces",
     "fixture_autograd_forces", "cells_h32", "cells_h16_train", "cells_z84_valence",
+    "fixture_shiftedsoftplus", "cells_h16_tanh_autograd_forces",       # round 2: activations other than SiLU
 ]
 
 

@@ -37,6 +37,8 @@ def _ocfg(cfg: dict) -> O.OracleConfig:
     kw = {k: v for k, v in cfg.items() if k in O.OracleConfig.__dataclass_fields__}
     if kw.get("rbf_type") == "sphericalbessel":
         kw["rbf_type"] = "bessel"
+    if "activation" in cfg and "extra" not in kw:
+        kw["extra"] = {"activation": cfg["activation"]}
     return O.OracleConfig(**kw)
 
 
@@ -186,7 +188,10 @@ def test_model_vs_reference_golden(golden_loader, dev, name):
         assert relerr(tr[f"x{i}"], g.ref(f"x{i}")) <= TOL, f"x{i}"
     assert relerr(out, g.ref("out")) <= TOL
     if force is not None:
-        assert relerr(force, g.ref("force")) <= TOL
+        if g.cfg.get("direct_forces", True):
+            assert relerr(force, g.ref("force")) <= TOL
+        else:   # autograd forces: against the reference's fp64 run (its own fp32 backward is noisy, see test_oracle_golden)
+            assert relerr(force, g.ref("force", "f64")) <= 5 * TOL
 
 
 def test_autograd_forces_vs_reference_golden(golden_loader, dev):

@@ -16,6 +16,8 @@ def _cfg(g: Golden) -> O.OracleConfig:
     kw = {k: v for k, v in g.cfg.items() if k in O.OracleConfig.__dataclass_fields__}
     if kw.get("rbf_type") == "sphericalbessel":
         kw["rbf_type"] = "bessel"
+    if "activation" in g.cfg:
+        kw["extra"] = {"activation": g.cfg["activation"]}
     return O.OracleConfig(**kw)
 
 
@@ -119,7 +121,14 @@ def test_model_golden(golden_loader, name, tag):
         assert tr["idx_k_3b"].numel() == int(g.ref("n_triplets", tag))
     assert relerr(out.detach(), g.ref("out", tag)) <= tol
     if force is not None:
-        assert relerr(force.detach(), g.ref("force", tag)) <= tol
+        if cfg.regress_forces and not cfg.direct_forces:
+            # autograd forces: compared with the reference's fp64 run in both precisions.  The reference's OWN fp32
+            # backward is 0.3-0.8 % away from its fp64 forces on random periodic cells (its radial basis re-evaluates the
+            # envelope once per orbital, and the D envelope-derivative terms that cancel analytically behind F.normalize
+            # leave rounding noise; profiles/r02/reference_fp32_force_noise.txt) — the restatement in fp32 stays within 5e-6.
+            assert relerr(force.detach(), g.ref("force", "f64")) <= (2e-5 if tag == "f32" else 1e-10)
+        else:
+            assert relerr(force.detach(), g.ref("force", tag)) <= tol
 
 
 def test_conditioning_near_cutoff(golden_loader):
