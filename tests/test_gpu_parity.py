@@ -159,7 +159,10 @@ def test_geometry_and_triplets(golden_loader, dev):
 
 
 # ------------------------------------------------------------------------------------------------ model
-@pytest.mark.parametrize("name", [c for c in MODEL_CASES if c != "fixture_autograd_forces"])
+AUTOGRAD_FORCE_CASES = ("fixture_autograd_forces", "cells_h16_tanh_autograd_forces")
+
+
+@pytest.mark.parametrize("name", [c for c in MODEL_CASES if c not in AUTOGRAD_FORCE_CASES])
 def test_model_vs_reference_golden(golden_loader, dev, name):
     """Every golden case produced by the reference itself, all model variants (valence, n_per_orb, max_orb,
     bessel, three cutoffs, atomref/mean, direct forces, train-mode BatchNorm)."""
@@ -194,14 +197,19 @@ def test_model_vs_reference_golden(golden_loader, dev, name):
             assert relerr(force, g.ref("force", "f64")) <= 5 * TOL
 
 
-def test_autograd_forces_vs_reference_golden(golden_loader, dev):
-    """regress_forces=True, direct_forces=False (lcaonet.py:310-317): F = -dE/dpos against the reference's own autograd."""
-    g = golden_loader("fixture_autograd_forces")
+@pytest.mark.parametrize("name", AUTOGRAD_FORCE_CASES)
+def test_autograd_forces_vs_reference_golden(golden_loader, dev, name):
+    """regress_forces=True, direct_forces=False (lcaonet.py:310-317): F = -dE/dpos against the reference's own autograd —
+    its fp64 run: on random periodic cells the reference's fp32 backward is itself 0.3-0.8 % off its fp64 forces
+    (profiles/r02/reference_fp32_force_noise.txt).  The second case uses Tanh activations (generic differentiable graph)."""
+    g = golden_loader(name)
     m = _model_from_golden(g, dev)
     out, force = m(_graph(g.graph(), dev))
     assert relerr(out, g.ref("out")) <= TOL
     assert force.shape == g.ref("force").shape
-    assert relerr(force, g.ref("force")) <= 5 * TOL    # a derivative: one order looser than the values
+    assert relerr(force, g.ref("force", "f64")) <= 5 * TOL    # a derivative: one order looser than the values
+    if name == "fixture_autograd_forces":
+        assert relerr(force, g.ref("force")) <= 5 * TOL       # on the 3-atom fixture the reference's fp32 run agrees too
 
 
 def _random_model(dev, seed, grad=False, **kw):
