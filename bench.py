@@ -450,12 +450,17 @@ def main():
         # every edge-level kernel against its own bound (per-launch averages of the separate fully bracketed pass, which
         # run ~3 % longer than in the timed region because of the event pairs): algorithmic work as in DESIGN.md section 4
         per_kernel = {}
+        H = model.emb_size
         work = {  # entry point: (bound, algorithmic flop or bytes per edge)
             "lcao_coeff_mlp_contract": ("mfma", 2.0 * D * (C * V + V * V)),
             "lcao_edge_lcao_weight": ("mfma", 4.0 * V * V),
             "lcao_edge_node_message": ("mfma", 2.0 * V * V),
+            "lcao_edge_node_message_agg": ("mfma", 2.0 * V * V),          # + the E -> N scatter, in the same kernel
             "lcao_triplet_gemm": ("hbm", 4 * n_l * V + 52 + 4 * V),
             "lcao_embed_coeffs": ("hbm", 4 * D * C),
+            # pos -> dist, unit vectors (caller's order + p-space), radial basis: 3 int32 + shift read, 4 + 12 + 12 + 4 D written
+            "lcao_edge_geometry_basis": ("hbm", 12 + 12 + 4 + 12 + 12 + 4 * D),
+            "lcao_node_tables": ("mfma", 2.0 * H * 3 * V * N / E),
         }
         for kname, (bound, per_edge) in work.items():
             if kname in kall and kall[kname][0] > 0:

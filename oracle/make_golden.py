@@ -192,6 +192,21 @@ def extra_cases():
     fx = graph_to_dict(reference_fixture_graph())
     small = dict(emb_size=16, emb_size_coeff=16, emb_size_conv=10, out_size=1, n_interaction=3, cutoff=6.0)
     run_case("fixture_shiftedsoftplus", fx, {**small, "activation": "ShiftedSoftplus"}, seed=40, keep_triplets=True)
+    # operator-level options LCAONet never sets: HydrogenRadialBasis(integral_norm=True) (rbf.py:88-89,107-127) and
+    # EnvelopeCutoff(p != 5) (cutoff.py:46-67); radial grid as in basis()
+    d = {}
+    ei = ElecInfo(96, None, None, 1)
+    rc = 5.0
+    r64 = torch.linspace(0.05, 1.1 * rc, 384, dtype=torch.float64)
+    d["r"] = r64.numpy()
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        r = r64.to(dt)
+        d[f"hydrogen_integral_norm_{tag}"] = HydrogenRadialBasis(rc, ei, EnvelopeCutoff(rc), integral_norm=True)(r).detach().numpy()
+        for p in (3, 7):
+            d[f"envelope_p{p}_{tag}"] = EnvelopeCutoff(rc, p)(r).numpy()
+            d[f"hydrogen_envelope_p{p}_{tag}"] = HydrogenRadialBasis(rc, ei, EnvelopeCutoff(rc, p))(r).numpy()
+    np.savez_compressed(os.path.join(OUT, "basis_options.npz"), **d)
+    print("basis_options: integral_norm, envelope p = 3, 7")
     g1 = graph_to_dict(random_periodic_cells(2, 12, 6.0, 0.99 * 5.0, max_z=36, seed=7))
     run_case("cells_h16_tanh_autograd_forces", g1,
              dict(emb_size=16, emb_size_coeff=16, emb_size_conv=16, n_interaction=2, cutoff=5.0, activation="Tanh",

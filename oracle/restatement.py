@@ -66,9 +66,8 @@ def nl_list(max_z: int, max_orb: str | None = None, n_per_orb: int = 1) -> list[
 # ----------------------------------------------------------------------------------------
 # cutoffs  (lcaonet/nn/cutoff.py)
 # ----------------------------------------------------------------------------------------
-def cutoff_fn(r: Tensor, rc: float, kind: str = "envelope") -> Tensor:
-    if kind == "envelope":  # cutoff.py:46-67, p = 5
-        p = 5
+def cutoff_fn(r: Tensor, rc: float, kind: str = "envelope", p: int = 5) -> Tensor:
+    if kind == "envelope":  # cutoff.py:46-67 (p = 5 is the default LCAONet uses)
         a = -(p + 1) * (p + 2) / 2
         b = p * (p + 2)
         c = -p * (p + 1) / 2
@@ -106,12 +105,30 @@ def hydrogen_norm(n: int, l: int, r0: float = 0.529) -> float:
     return -math.sqrt((2.0 / n / r0) ** 3 * math.factorial(n - l - 1) / 2.0 / n / math.factorial(n + l) ** 3)
 
 
+def sphere_norm(n: int, l: int, rc: float, cutoff: str = "envelope", r0: float = 0.529, p: int = 5) -> float:
+    """rbf.py:88-89,107-127 (integral_norm=True): the prefactor is -2/(n r0) and the orbital is rescaled by
+    1 / (sqrt(int_0^rc (r f(r))^2 dr) + 1e-12), the integral by scipy.integrate.quad over the cutoff-weighted orbital."""
+    from scipy.integrate import quad
+
+    c = laguerre_poly_coeffs(n, l)
+    pre = -2.0 / n / r0
+
+    def f(x: float) -> float:
+        zeta = 2.0 / n / r0 * x
+        cw = float(cutoff_fn(torch.tensor([x], dtype=torch.float64), rc, cutoff, p))
+        return cw * pre * sum(ci * zeta**i for i, ci in enumerate(c)) * zeta**l * math.exp(-zeta / 2.0)
+
+    integral = quad(lambda x: (x * f(x)) ** 2, 0.0, rc)[0]
+    sc = 1 / (torch.sqrt(torch.tensor([integral])) + 1e-12)       # a float32 tensor in the reference (rbf.py:127)
+    return pre * float(sc)
+
+
 def hydrogen_radial_basis(r: Tensor, nl: list[tuple[int, int]], rc: float, cutoff: str = "envelope",
-                          r0: float = 0.529) -> Tensor:
+                          r0: float = 0.529, integral_norm: bool = False, p: int = 5) -> Tensor:
     """rbf.py:96-103,129-142.  The lambdified sympy polynomial is evaluated in expanded
     monomial form, highest power first, with x**k — kept that way here."""
     cols = []
-    cw = cutoff_fn(r, rc, cutoff)
+    cw = cutoff_fn(r, rc, cutoff, p)
     for n, l in nl:
         zeta = 2.0 / n / r0 * r
         c = laguerre_poly_coeffs(n, l)
@@ -124,7 +141,8 @@ def hydrogen_radial_basis(r: Tensor, nl: list[tuple[int, int]], rc: float, cutof
             else:
                 term = c[i] * zeta**i
             poly = term if poly is None else poly + term
-        cols.append(cw * hydrogen_norm(n, l, r0) * poly * torch.pow(zeta, l) * torch.exp(-zeta / 2.0))
+        norm = sphere_norm(n, l, rc, cutoff, r0, p) if integral_norm else hydrogen_norm(n, l, r0)
+        cols.append(cw * norm * poly * torch.pow(zeta, l) * torch.exp(-zeta / 2.0))
     return torch.stack(cols, dim=1)
 
 

@@ -170,3 +170,26 @@ def test_radial_basis_flat_tolerance_inside_095_rc(golden_loader, dev, rc, cut):
     assert ei.n_orb == 18 and int(keep.sum()) > 300          # 331 of the 384 grid points
     for d in range(ei.n_orb):
         assert relerr(rb[keep, d], ref[keep, d]) <= TOL, (d, relerr(rb[keep, d], ref[keep, d]))
+
+
+def test_basis_options_vs_reference_tables(golden_loader, dev):
+    """Operator-level options LCAONet itself never sets: HydrogenRadialBasis(integral_norm=True) (rbf.py:107-127: each
+    orbital normalised over the cutoff sphere) and EnvelopeCutoff(p != 5) (cutoff.py:46-67), against tables dumped from the
+    reference; flat 1e-5 per orbital on the whole grid."""
+    from lcaonet_amd.atomistic.info import ElecInfo
+    from lcaonet_amd.nn.cutoff import EnvelopeCutoff
+    from lcaonet_amd.nn.rbf import HydrogenRadialBasis
+    z = golden_loader("basis_options").z
+    r = torch.from_numpy(z["r"]).float().to(dev)
+    ei = ElecInfo(96, None, None, 1)
+    rb = HydrogenRadialBasis(5.0, ei, EnvelopeCutoff(5.0), integral_norm=True).to(dev)(r)
+    ref = torch.from_numpy(z["hydrogen_integral_norm_f32"])
+    for d in range(ei.n_orb):
+        assert relerr(rb[:, d], ref[:, d]) <= TOL, ("integral_norm", d, relerr(rb[:, d], ref[:, d]))
+    for p in (3, 7):
+        cn = EnvelopeCutoff(5.0, p)
+        assert relerr(cn(r), z[f"envelope_p{p}_f32"]) <= TOL
+        rb = HydrogenRadialBasis(5.0, ei, cn).to(dev)(r)
+        ref = torch.from_numpy(z[f"hydrogen_envelope_p{p}_f32"])
+        for d in range(ei.n_orb):
+            assert relerr(rb[:, d], ref[:, d]) <= TOL, (p, d, relerr(rb[:, d], ref[:, d]))

@@ -141,3 +141,23 @@ def test_conditioning_near_cutoff(golden_loader):
     e_trim = relerr(trimmed.ref("x2", "f32"), trimmed.ref("x2", "f64"))
     assert e_trim < 1e-5
     print(f"reference fp32-vs-fp64: full shell {e_full:.2e}, trimmed {e_trim:.2e}")
+
+
+def test_basis_options_golden(golden_loader):
+    """HydrogenRadialBasis(integral_norm=True) (rbf.py:88-89,107-127) and EnvelopeCutoff(p) (cutoff.py:46-67) against tables
+    dumped from the reference (oracle/make_golden.py extra).  The reference's normalisation constant is a float32 tensor
+    and its quadrature integrand evaluates the cutoff in float32, so the fp64 table agrees to ~1e-7, not 1e-11."""
+    z = golden_loader("basis_options").z
+    nl = O.nl_list(96)
+    for tag, dt, tol in (("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-6)):
+        r = torch.from_numpy(z["r"]).to(dt)
+        got = O.hydrogen_radial_basis(r, nl, 5.0, "envelope", integral_norm=True)
+        ref = torch.from_numpy(z[f"hydrogen_integral_norm_{tag}"])
+        for d in range(len(nl)):
+            assert relerr(got[:, d], ref[:, d]) <= tol, (tag, d)
+        for p in (3, 7):
+            assert relerr(O.cutoff_fn(r, 5.0, "envelope", p), z[f"envelope_p{p}_{tag}"]) <= (1e-6 if tag == "f32" else 1e-12)
+            got = O.hydrogen_radial_basis(r, nl, 5.0, "envelope", p=p)
+            ref = torch.from_numpy(z[f"hydrogen_envelope_p{p}_{tag}"])
+            for d in range(len(nl)):
+                assert relerr(got[:, d], ref[:, d]) <= (2e-5 if tag == "f32" else 1e-11), (tag, p, d)
