@@ -191,5 +191,10 @@ def test_basis_options_vs_reference_tables(golden_loader, dev):
         assert relerr(cn(r), z[f"envelope_p{p}_f32"]) <= TOL
         rb = HydrogenRadialBasis(5.0, ei, cn).to(dev)(r)
         ref = torch.from_numpy(z[f"hydrogen_envelope_p{p}_f32"])
+        ref64 = torch.from_numpy(z[f"hydrogen_envelope_p{p}_f64"])
         for d in range(ei.n_orb):
-            assert relerr(rb[:, d], ref[:, d]) <= TOL, (p, d, relerr(rb[:, d], ref[:, d]))
+            # the kernel's factored envelope is exact to 3e-7, so the distance to the reference's fp32 table IS the reference's
+            # fp32-vs-fp64 noise — 6.2e-6 at p = 3, 1.16e-5 at p = 7 (terms of 63 in the expanded form), orbital 4f
+            noise = relerr(ref[:, d], ref64[:, d])
+            assert relerr(rb[:, d], ref[:, d]) <= max(TOL, 1.02 * noise), (p, d, relerr(rb[:, d], ref[:, d]), noise)
+            assert relerr(rb[:, d], ref64[:, d]) <= max(0.5 * noise, 1e-6), (p, d)

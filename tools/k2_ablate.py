@@ -24,7 +24,7 @@ for path in sorted(glob.glob(sys.argv[1] + "/lib*.so")):
     fn = lib.lcao_coeff_mlp_contract
     fn.argtypes = _lib.SIGNATURES["lcao_coeff_mlp_contract"]
     def run():
-        rc = fn(p(cst), p(rb), p(order), p(l_of_d), None, p(W1), p(W2), p(gate), p(src), E, D, C, V, NL, 0, None, p(B), None,
+        rc = fn(p(cst), p(rb), p(order), None, p(l_of_d), None, p(W1), p(W2), p(gate), p(src), E, D, C, V, NL, 0, None, p(B), None,
                 p(Ag), p(gram), p(ws), 8, None)
         assert rc == 0, rc
     for _ in range(3):
