@@ -2,6 +2,8 @@
 // weight tile = MFMA A operand from LDS, 16 data rows = B operand from global memory, accumulator layout of one layer
 // = B-operand layout of the next.
 #pragma once
+#include <cstdlib>
+
 #include "lcao_common.h"
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -31,6 +33,10 @@ __device__ __forceinline__ float lcao_silu_log2e(float xs) {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Number of CUs the persistent kernels size their grids for.  LCAO_CU_RESERVE=k leaves k CUs out: the persistent
+// coefficient kernel fills every SIMD's register file (2 waves x 256 VGPRs), so a collective's copy kernels launched on
+// another stream (the halo exchange of a sharded graph, lcaonet_amd/shard.py) find no slot until it ends unless some CUs
+// are kept free.  Default 0 (single-GPU runs); untested on multi-GPU hardware.
 static inline int lcao_num_cu() {
   static int g_num_cu = 0;
   if (g_num_cu == 0) {
@@ -39,6 +45,9 @@ static inline int lcao_num_cu() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       g_num_cu = prop.multiProcessorCount;
     if (g_num_cu <= 0) g_num_cu = 256;
+    const char* e = getenv("LCAO_CU_RESERVE");
+    const int reserve = e ? atoi(e) : 0;
+    if (reserve > 0 && reserve < g_num_cu) g_num_cu -= reserve;
   }
   return g_num_cu;
 }
