@@ -371,7 +371,7 @@ def main():
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t1) / args.steps, err
 
-    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = mat_ms = mat_err = None
+    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = mat_ms = mat_err = h_ms = h_err = None
     secondary_error = None
     kall = {}
     if rank == 0 and not args.no_secondary:
@@ -384,6 +384,7 @@ def main():
                 mat_ms, mat_err = timed(cst_mode="edge_tensor")              # cst materialised per edge as the reference holds it
                 pair_ms, pair_err = timed(cst_mode="pair")                   # species-pair table
                 bf_ms, bf_err = timed(precision="bf16x3")                    # BASELINE config 3
+                h_ms, h_err = timed(precision="f16")                         # ... at its stated tolerance (1e-3)
                 bp_ms, bp_err = timed(precision="bf16x3", cst_mode="pair")
             if not with_forces and args.workload == "cfg2":
                 # rows f3 of SURVEY.md 8: energy + autograd forces (reverse sweep) and one full training step, same batch
@@ -517,6 +518,12 @@ def main():
             "with_pair_table": None if bp_ms is None else {
                 "ms_per_step_rank0": round(bp_ms, 3), "edges_per_s_rank0": E / (bp_ms * 1e-3),
                 "max_rel_diff_vs_fp32_output": bp_err}}
+        if h_ms is not None:
+            line["f16_mode"] = {
+                "note": "NOT the headline: BASELINE config 3 at its stated tolerance (1e-3) — the per-edge GEMMs with operands rounded "
+                        "once to fp16, ONE v_mfma_f32_16x16x32_f16 per product, fp32 accumulation; general per-edge cst",
+                "dtype": "f16", "ms_per_step_rank0": round(h_ms, 3), "edges_per_s_rank0": E / (h_ms * 1e-3),
+                "max_rel_diff_vs_fp32_output": h_err}
         if forces_ms is not None:
             line["autograd_forces_mode"] = {
                 "note": "NOT the headline: regress_forces=True, direct_forces=False — energy and F = -dE/dpos by the HIP reverse "

@@ -215,6 +215,19 @@ int lcao_triplet_gemm(const float* Ag, const float* gram, const float* uvec_p, c
                       const int32_t* in_pos, const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int V, int n_l,
                       float* tbw, void* stream);
 
+/* BASELINE config 3 at its STATED tolerance (1e-3): the same three fused kernels with operands rounded once to fp16 and ONE
+ * v_mfma_f32_16x16x32_f16 per product (fp32 accumulation): ~3e-4 from fp32, where a single bf16 MFMA (3.6e-3 on the MLP
+ * alone) does not meet the tolerance.  Same arguments as the _bf16x3 forms. */
+int lcao_coeff_mlp_contract_f16(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+                                const int32_t* l_of_d, const float* W1, const float* W2, const float* gate,
+                                const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, float* A, float* B,
+                                float* Ag, float* gram, void* workspace, size_t ws_bytes, void* stream);
+int lcao_edge_lcao_weight_f16(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges, int V,
+                              float* bw, void* stream);
+int lcao_edge_node_message_f16(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                               const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V, float* msg,
+                               void* stream);
+
 /* bf16x3 forms of the two fused two-body kernels below (same arguments, same split as lcao_coeff_mlp_contract_bf16x3) */
 int lcao_edge_lcao_weight_bf16x3(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges,
                                  int V, float* bw, void* stream);

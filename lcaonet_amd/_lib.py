@@ -43,6 +43,9 @@ SIGNATURES = {
     "lcao_triplet_literal": [P, P, P, P, L, P, P, P, L, L, L, L, I, I, I, P, P],
     "lcao_coeff_mlp_contract": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P],
     "lcao_coeff_mlp_contract_bf16x3": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, c_size_t, P],
+    "lcao_coeff_mlp_contract_f16": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, c_size_t, P],
+    "lcao_edge_lcao_weight_f16": [P, P, P, P, L, I, P, P],
+    "lcao_edge_node_message_f16": [P, P, P, P, P, P, P, L, I, P, P],
     "lcao_triplet_gemm": [P, P, P, P, P, P, L, L, I, I, P, P],
     "lcao_pair_contract": [P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],
     "lcao_pair_contract_visit": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P],

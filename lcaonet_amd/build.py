@@ -9,7 +9,7 @@ import time
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(CSRC, "liblcaonet_hip.so")
-SOURCES = ["lcao_generic.hip", "lcao_mfma.hip", "lcao_node.hip", "lcao_csr.hip", "lcao_neighbors.hip", "lcao_backward.hip", "lcao_double.hip"]
+SOURCES = ["lcao_generic.hip", "lcao_mfma.hip", "lcao_lowp.hip", "lcao_node.hip", "lcao_csr.hip", "lcao_neighbors.hip", "lcao_backward.hip", "lcao_double.hip"]
 
 
 def _newer(a: str, b: str) -> bool:

@@ -1701,437 +1701,3 @@ extern "C" int lcao_wgrad(const float* G, const float* X, int64_t n_rows, int M,
                      dW);
   return lcao_launch_status();
 }
-
-// ===================================================================================================
-// lcao_coeff_mlp_contract_bf16x3 — BASELINE config 3 ("bf16 MFMA on the per-edge coeffs x hidden GEMM"):
-// the same fused kernel as lcao_coeff_mlp_contract with both Dense layers on v_mfma_f32_16x16x32_bf16.
-// Plain bf16 operands cost 3.6e-3 relative error on this MLP (worse than config 3's own 1e-3 bound), so every fp32
-// operand is split into two bf16 terms, x = xh + xl (16 mantissa bits), and a product runs as three MFMAs with fp32
-// accumulation:  wh.xl + wl.xh + wh.xh  (the dropped wl.xl is 2^-16 of the product): 6-9e-6 relative error on the
-// two-layer MLP at 3/16 of the fp32 matrix time ("bf16x3").  Weights are split once per workgroup while staging
-// (hi/lo planes, 139 KB of LDS at C = V = 128); activations are split in registers.
-//   layer 1, k-step s (32 inputs):  lane (n, g) feeds X[n][32s + 8g + j], j < 8      (natural order, 32 B per lane)
-//   layer 2, k-step s (32 hidden):  lane (n, g) feeds h tile 2s regs 0..3 (features 32s + 4g + j) and h tile 2s+1
-//                                   regs 0..3 (features 32s + 16 + 4g + j): the W2 planes are stored column-permuted
-//                                   to match, so layers still chain register to register.
-// ===================================================================================================
-typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
-#define MFMA16BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8v& hi, bf16x8v& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)x[j];
-    hi[j] = h;
-    lo[j] = (__bf16)(x[j] - (float)h);
-  }
-}
-
-// LDS plane layout: [row][K + 8] bf16 (272-B rows at K = 128: 16 rows of a fragment hit 16 distinct 16-B slots)
-template <bool PERMUTE>
-__device__ __forceinline__ void stage_weights_bf16x2(__bf16* __restrict__ hi, __bf16* __restrict__ lo,
-                                                     const float* __restrict__ W, int rows, int K) {
-  const int ld = K + 8;
-  for (int i = threadIdx.x; i < rows * K; i += blockDim.x) {
-    const int rr = i / K, pos = i - rr * K;
-    int col = pos;
-    if (PERMUTE) {  // pos = 32 s + 8 g + j  ->  column 32 s + (j < 4 ? 4 g + j : 16 + 4 g + (j - 4))
-      const int s = pos >> 5, g = (pos >> 3) & 3, j = pos & 7;
-      col = 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
-    }
-    const float w = W[(int64_t)rr * K + col];
-    const __bf16 h = (__bf16)w;
-    hi[rr * ld + pos] = h;
-    lo[rr * ld + pos] = (__bf16)(w - (float)h);
-  }
-}
-
-template <int C, int V, int NL, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_coeff_mlp_bf16x3(
-    const float* __restrict__ cst, const float* __restrict__ rb, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ cst_row, const int32_t* __restrict__ l_of_d, const float* __restrict__ W1,
-    const float* __restrict__ W2, int64_t E, int D, float* __restrict__ A, float* __restrict__ Bout,
-    const float* __restrict__ gate, const int32_t* __restrict__ src_p, float* __restrict__ Ag, float* __restrict__ gram,
-    unsigned* __restrict__ tile_counter) {
-  static_assert(C % 32 == 0 && V % 32 == 0, "k-steps are 32 wide");
-  constexpr int KS1 = C / 32, KS2 = V / 32, MT = V / 16, LD1 = C + 8, LD2 = V + 8, WAVES = THREADS / 64;
-  extern __shared__ __bf16 ldsb[];
-  __bf16* w1h = ldsb;
-  __bf16* w1l = w1h + V * LD1;
-  __bf16* w2h = w1l + V * LD1;
-  __bf16* w2l = w2h + V * LD2;
-  stage_weights_bf16x2<false>(w1h, w1l, W1, V, C);
-  stage_weights_bf16x2<true>(w2h, w2l, W2, V, V);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int64_t n_tiles = (E + 15) >> 4;
-  const int64_t first_dynamic = (int64_t)gridDim.x * WAVES;
-  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
-  for (; tile < n_tiles;) {
-    const int64_t p = tile * 16 + r;
-    const bool valid = p < E;
-    const int64_t pc = valid ? p : E - 1;
-    const int64_t e = order ? order[pc] : pc;
-    const int64_t ec = cst_row ? (int64_t)cst_row[pc] : e;   // gathered coefficient rows (see k_coeff_mlp)
-    const float* xrow = cst + ec * (int64_t)D * C + 8 * q;
-    const float* rbrow = rb + e * D;
-    f32x4v acc[NL][MT];
-#pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[l][m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    f32x4v x[KS1][2];
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) {
-      x[s][0] = *(const f32x4v*)(xrow + 32 * s);
-      x[s][1] = *(const f32x4v*)(xrow + 32 * s + 4);
-    }
-    for (int d = 0; d < D; ++d) {
-      asm volatile("" ::: "memory");  // the LDS fragments are loop-invariant: keep them from being hoisted (spills)
-      f32x4v h[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) h[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < KS1; ++s) {
-        float xf[8] = {x[s][0][0], x[s][0][1], x[s][0][2], x[s][0][3], x[s][1][0], x[s][1][1], x[s][1][2], x[s][1][3]};
-        bf16x8v xh, xl;
-        split8(xf, xh, xl);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const bf16x8v wh = *(const bf16x8v*)(w1h + (16 * m + r) * LD1 + 32 * s + 8 * q);
-          const bf16x8v wl = *(const bf16x8v*)(w1l + (16 * m + r) * LD1 + 32 * s + 8 * q);
-          h[m] = MFMA16BF(wh, xl, h[m]);
-          h[m] = MFMA16BF(wl, xh, h[m]);
-          h[m] = MFMA16BF(wh, xh, h[m]);
-        }
-      }
-      if (d + 1 < D) {
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-          x[s][0] = *(const f32x4v*)(xrow + (d + 1) * C + 32 * s);
-          x[s][1] = *(const f32x4v*)(xrow + (d + 1) * C + 32 * s + 4);
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h[m][j] = lcao_silu(h[m][j]);
-      f32x4v o[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < KS2; ++s) {
-        float hf[8] = {h[2 * s][0], h[2 * s][1], h[2 * s][2], h[2 * s][3],
-                       h[2 * s + 1][0], h[2 * s + 1][1], h[2 * s + 1][2], h[2 * s + 1][3]};
-        bf16x8v hh, hl;
-        split8(hf, hh, hl);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const bf16x8v wh = *(const bf16x8v*)(w2h + (16 * m + r) * LD2 + 32 * s + 8 * q);
-          const bf16x8v wl = *(const bf16x8v*)(w2l + (16 * m + r) * LD2 + 32 * s + 8 * q);
-          o[m] = MFMA16BF(wh, hl, o[m]);
-          o[m] = MFMA16BF(wl, hh, o[m]);
-          o[m] = MFMA16BF(wh, hh, o[m]);
-        }
-      }
-      const float w = rbrow[d];
-      const int l = l_of_d[d];
-#pragma unroll
-      for (int ll = 0; ll < NL; ++ll) {
-        if (l == ll) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ll][m][j] += w * lcao_silu(o[m][j]);
-        }
-      }
-    }
-    // epilogue: identical to k_coeff_mlp (B, Gram of the ungated A, gated copy or raw A)
-    f32x4v bsum[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      bsum[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int l = 0; l < NL; ++l) bsum[m] += acc[l][m];
-    }
-    if (gram) {
-      float g[10];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) g[i] = 0.f;
-      int gi = 0;
-#pragma unroll
-      for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int l2 = l; l2 < 4; ++l2) {
-          if (l < NL && l2 < NL) {
-            float t = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) t += acc[l][m][j] * acc[l2][m][j];
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            g[gi] = t;
-          }
-          ++gi;
-        }
-      if (valid && q == 0) {
-        float* gp = gram + p * 10;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) gp[i] = g[i];
-      }
-    }
-    if (valid) {
-      float* Bp = Bout + p * (int64_t)V + 4 * q;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        *(f32x4v*)(Bp + 16 * m) = bsum[m];
-        if (Ag) {
-          const f32x4v gt = *(const f32x4v*)(gate + (int64_t)src_p[p] * V + 16 * m + 4 * q);
-          float* Agp = Ag + p * (int64_t)NL * V + 4 * q;
-#pragma unroll
-          for (int l = 0; l < NL; ++l) *(f32x4v*)(Agp + l * V + 16 * m) = acc[l][m] * gt;
-        } else {
-          float* Ap = A + p * (int64_t)NL * V + 4 * q;
-#pragma unroll
-          for (int l = 0; l < NL; ++l) *(f32x4v*)(Ap + l * V + 16 * m) = acc[l][m];
-        }
-      }
-    }
-    unsigned nxt = 0;
-    if (lane == 0) nxt = atomicAdd(tile_counter, 1u);
-    tile = first_dynamic + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
-  }
-}
-
-template <int C, int V, int NL>
-static int launch_coeff_mlp_bf(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
-                               const int32_t* l_of_d, const float* W1, const float* W2, int64_t E, int D, float* A, float* Bout,
-                               const float* gate, const int32_t* src_p, float* Ag, float* gram, unsigned* counter,
-                               hipStream_t st) {
-  constexpr int THREADS = 512;
-  size_t lds = (size_t(2) * V * (C + 8) + size_t(2) * V * (V + 8)) * sizeof(__bf16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_coeff_mlp_bf16x3<C, V, NL, THREADS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return int(e);
-    attr_set = true;
-  }
-  constexpr int WAVES = THREADS / 64;
-  int64_t tiles = (E + 15) / 16;
-  int64_t groups = (tiles + WAVES - 1) / WAVES;
-  int64_t cap = (int64_t)lcao_num_cu() * ((lds > 80 * 1024) ? 1 : 2);
-  if (groups > cap) groups = cap;
-  hipError_t me = hipMemsetAsync(counter, 0, sizeof(unsigned), st);
-  if (me != hipSuccess) return int(me);
-  hipLaunchKernelGGL((k_coeff_mlp_bf16x3<C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb,
-                     order, cst_row, l_of_d, W1, W2, E, D, A, Bout, gate, src_p, Ag, gram, counter);
-  return lcao_launch_status();
-}
-
-extern "C" int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order,
-                                              const int32_t* cst_row, const int32_t* l_of_d, const float* W1, const float* W2,
-                                              const float* gate, const int32_t* src_p, int64_t n_edges, int n_orb, int C,
-                                              int V, int n_l, float* A, float* B, float* Ag, float* gram,
-                                              void* workspace, size_t ws_bytes, void* stream) {
-  LCAO_CHECK_SIZE(n_edges);
-  if (n_orb <= 0 || C <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
-  if (n_edges == 0) return LCAO_OK;
-  LCAO_CHECK_PTR(cst); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(W1); LCAO_CHECK_PTR(W2);
-  LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(workspace);
-  if (Ag) { LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(gram); } else { LCAO_CHECK_PTR(A); }
-  if (ws_bytes < sizeof(unsigned)) return LCAO_ERR_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  unsigned* ctr = (unsigned*)workspace;
-#define BF_CASE(C_, V_, NL_)                                                                                       \
-  if (C == C_ && V == V_ && n_l == NL_)                                                                            \
-    return launch_coeff_mlp_bf<C_, V_, NL_>(cst, rb, order, cst_row, l_of_d, W1, W2, n_edges, n_orb, A, B, gate, src_p, Ag, \
-                                            Ag ? gram : nullptr, ctr, st);
-#define BF_CV(C_, V_) BF_CASE(C_, V_, 1) BF_CASE(C_, V_, 2) BF_CASE(C_, V_, 3) BF_CASE(C_, V_, 4)
-  BF_CV(128, 128) BF_CV(64, 64) BF_CV(32, 32)
-#undef BF_CV
-#undef BF_CASE
-  return LCAO_ERR_UNSUPPORTED;
-}
-
-// ===================================================================================================
-// bf16x3 forms of the two-body kernels (same split as k_coeff_mlp_bf16x3; `precision="bf16x3"`).
-// bf_layer: one Dense layer on a 16-row tile, input given as 8 floats per 32-wide k-step in B-operand order.
-// ===================================================================================================
-template <int KS, int MT>
-__device__ __forceinline__ void bf_layer(const __bf16* __restrict__ wh, const __bf16* __restrict__ wl, int ld, int r,
-                                         int q, const float (&in)[KS][8], f32x4v (&out)[MT]) {
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    bf16x8v xh, xl;
-    split8(in[s], xh, xl);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const bf16x8v a_h = *(const bf16x8v*)(wh + (16 * m + r) * ld + 32 * s + 8 * q);
-      const bf16x8v a_l = *(const bf16x8v*)(wl + (16 * m + r) * ld + 32 * s + 8 * q);
-      out[m] = MFMA16BF(a_h, xl, out[m]);
-      out[m] = MFMA16BF(a_l, xh, out[m]);
-      out[m] = MFMA16BF(a_h, xh, out[m]);
-    }
-  }
-}
-
-template <int V>
-__global__ __launch_bounds__(256) void k_edge_lcao_weight_bf(const float* __restrict__ tbw, const float* __restrict__ B,
-                                                             const float* __restrict__ W3, const float* __restrict__ Wb,
-                                                             int64_t E, float* __restrict__ bw) {
-  constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
-  extern __shared__ __bf16 ldsb[];
-  __bf16* w3h = ldsb;
-  __bf16* w3l = w3h + V * LD;
-  __bf16* wbh = w3l + V * LD;
-  __bf16* wbl = wbh + V * LD;
-  stage_weights_bf16x2<false>(w3h, w3l, W3, V, V);
-  stage_weights_bf16x2<true>(wbh, wbl, Wb, V, V);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int64_t n_tiles = (E + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-    asm volatile("" ::: "memory");
-    const int64_t p = tile * 16 + r;
-    const bool valid = p < E;
-    const int64_t pc = valid ? p : E - 1;
-    float xin[KS][8];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const f32x4v a = *(const f32x4v*)(tbw + pc * V + 32 * s + 8 * q);
-      const f32x4v b = *(const f32x4v*)(tbw + pc * V + 32 * s + 8 * q + 4);
-      xin[s][0] = a[0]; xin[s][1] = a[1]; xin[s][2] = a[2]; xin[s][3] = a[3];
-      xin[s][4] = b[0]; xin[s][5] = b[1]; xin[s][6] = b[2]; xin[s][7] = b[3];
-    }
-    f32x4v bb[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) bb[m] = *(const f32x4v*)(B + pc * V + 16 * m + 4 * q);
-    f32x4v ft[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) ft[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    bf_layer<KS, MT>(w3h, w3l, LD, r, q, xin, ft);
-    float n2 = 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float u = bb[m][j] + bb[m][j] * ft[m][j];
-        ft[m][j] = u;
-        n2 += u * u;
-      }
-    n2 += __shfl_xor(n2, 16);
-    n2 += __shfl_xor(n2, 32);
-    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
-    float lin[KS][8];
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lin[s][j] = ft[2 * s][j] * inv;
-        lin[s][4 + j] = ft[2 * s + 1][j] * inv;
-      }
-    f32x4v o[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    bf_layer<KS, MT>(wbh, wbl, LD, r, q, lin, o);
-    if (valid) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) *(f32x4v*)(bw + p * V + 16 * m + 4 * q) = o[m];
-    }
-  }
-}
-
-template <int V>
-__global__ __launch_bounds__(256) void k_edge_node_message_bf(
-    const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
-    const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, const float* __restrict__ Wn2,
-    const float* __restrict__ bn2, int64_t E, float* __restrict__ msg) {
-  constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
-  extern __shared__ __bf16 ldsb[];
-  __bf16* wh = ldsb;
-  __bf16* wl = wh + V * LD;
-  stage_weights_bf16x2<false>(wh, wl, Wn2, V, V);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int64_t n_tiles = (E + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-    asm volatile("" ::: "memory");
-    const int64_t p = tile * 16 + r;
-    const bool valid = p < E;
-    const int64_t pc = valid ? p : E - 1;
-    const float* ps = Ps + (int64_t)src_p[pc] * V + 8 * q;
-    const float* pt = Pt + (int64_t)dst_p[pc] * V + 8 * q;
-    float hin[KS][8];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const f32x4v a = *(const f32x4v*)(ps + 32 * s) + *(const f32x4v*)(pt + 32 * s);
-      const f32x4v b = *(const f32x4v*)(ps + 32 * s + 4) + *(const f32x4v*)(pt + 32 * s + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { hin[s][j] = lcao_silu(a[j]); hin[s][4 + j] = lcao_silu(b[j]); }
-    }
-    f32x4v o[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
-    bf_layer<KS, MT>(wh, wl, LD, r, q, hin, o);
-    if (valid) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        f32x4v w = *(const f32x4v*)(bw + p * V + 16 * m + 4 * q);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] *= lcao_silu(o[m][j]);
-        *(f32x4v*)(msg + p * V + 16 * m + 4 * q) = w;
-      }
-    }
-  }
-}
-
-extern "C" int lcao_edge_lcao_weight_bf16x3(const float* tbw, const float* B, const float* W3, const float* Wb,
-                                            int64_t n_edges, int V, float* bw, void* stream) {
-  LCAO_CHECK_SIZE(n_edges);
-  if (V <= 0) return LCAO_ERR_INVALID;
-  if (n_edges == 0) return LCAO_OK;
-  LCAO_CHECK_PTR(tbw); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(W3); LCAO_CHECK_PTR(Wb); LCAO_CHECK_PTR(bw);
-  hipStream_t st = (hipStream_t)stream;
-  size_t lds = size_t(4) * V * (V + 8) * sizeof(__bf16);
-#define LWB_CASE(V_)                                                                                            \
-  if (V == V_) {                                                                                                \
-    static bool done = false;                                                                                   \
-    int rc = set_lds_attr(k_edge_lcao_weight_bf<V_>, lds, done);                                                \
-    if (rc != LCAO_OK) return rc;                                                                               \
-    hipLaunchKernelGGL(k_edge_lcao_weight_bf<V_>, dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, tbw, B, \
-                       W3, Wb, n_edges, bw);                                                                    \
-    return lcao_launch_status();                                                                                \
-  }
-  LWB_CASE(128) LWB_CASE(64) LWB_CASE(32)
-#undef LWB_CASE
-  return LCAO_ERR_UNSUPPORTED;
-}
-
-extern "C" int lcao_edge_node_message_bf16x3(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
-                                             const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges,
-                                             int V, float* msg, void* stream) {
-  LCAO_CHECK_SIZE(n_edges);
-  if (V <= 0) return LCAO_ERR_INVALID;
-  if (n_edges == 0) return LCAO_OK;
-  LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p);
-  LCAO_CHECK_PTR(Wn2); LCAO_CHECK_PTR(bn2); LCAO_CHECK_PTR(msg);
-  hipStream_t st = (hipStream_t)stream;
-  size_t lds = size_t(2) * V * (V + 8) * sizeof(__bf16);
-#define NMB_CASE(V_)                                                                                              \
-  if (V == V_) {                                                                                                  \
-    static bool done = false;                                                                                     \
-    int rc = set_lds_attr(k_edge_node_message_bf<V_>, lds, done);                                                 \
-    if (rc != LCAO_OK) return rc;                                                                                 \
-    hipLaunchKernelGGL(k_edge_node_message_bf<V_>, dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, bw, Ps, \
-                       Pt, src_p, dst_p, Wn2, bn2, n_edges, msg);                                                 \
-    return lcao_launch_status();                                                                                  \
-  }
-  NMB_CASE(128) NMB_CASE(64) NMB_CASE(32)
-#undef NMB_CASE
-  return LCAO_ERR_UNSUPPORTED;
-}

@@ -291,7 +291,7 @@ class LCAOInteraction(nn.Module):
         E, dev = ctx.n_edges, x.device
         if fused is None:
             fused = self._fusable(V if pair is not None else cst.shape[-1])
-        if cst_row is not None and (pair is not None or not fused or (precision == "bf16x3" and self.add_valence)):
+        if cst_row is not None and (pair is not None or not fused or (precision in ops.LOWP and self.add_valence)):
             raise ValueError("forward_fused: cst_row needs the fused per-edge coefficient kernel")
         split = (ghost_fn is not None and fused and pair is None and precision == "fp32" and not exact_norm
                  and not self.add_valence and N > n_own)
@@ -331,11 +331,11 @@ class LCAOInteraction(nn.Module):
                 Ag, gram, B = pc(Tf)
                 Bv = None
             tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
-        elif fused and precision == "bf16x3" and not self.add_valence and cst.shape[-1] == V:
-            # BASELINE config 3: bf16 MFMA on the per-edge coefficient GEMMs, operands split into two bf16 terms
+        elif fused and precision in ops.LOWP and not self.add_valence and cst.shape[-1] == V:
+            # BASELINE config 3: 16-bit MFMA on the per-edge coefficient GEMMs (bf16 split in two terms, or plain fp16)
             Ag, gram, B, Bv = ops.coeff_mlp_contract_bf16x3(
                 cst, rb, ctx.order, l_of_d, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(), n_l,
-                gate=None if exact_norm else gate, src_p=ctx.src_p, cst_row=cst_row)
+                gate=None if exact_norm else gate, src_p=ctx.src_p, cst_row=cst_row, precision=precision)
             if exact_norm:
                 tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
             else:
@@ -566,8 +566,10 @@ class LCAONet(BaseMPNN):
         kernel, so the (E, D, C) tensor is never materialised.  "edge_tensor": the same with cst materialised per edge as
         the reference holds it.  "pair": f_coeffs evaluated on the pair table itself (fewer flops).
 
-        precision: "fp32" (default; exact fp32 MFMA) or "bf16x3" (BASELINE config 3: the per-edge coefficient GEMMs on
-        bf16 MFMA with two-term operand splitting; ~1e-5 from fp32 where plain bf16 would be 4e-3).
+        precision: "fp32" (default; exact fp32 MFMA); BASELINE config 3 modes, the per-edge GEMMs on the 16-bit matrix
+        path: "bf16x3" (bf16 MFMA with two-term operand splitting, three MFMAs per product: ~1e-5 from fp32, where plain
+        bf16 would be 4e-3) or "f16" (operands rounded once to fp16, one MFMA per product: ~3e-4, inside the config's
+        stated 1e-3).
 
         differentiable (default: autograd is enabled and some parameter requires grad — what the reference does in
         train AND eval mode, lcaonet.py:488-540): record an autograd graph to every parameter (model/train.py: HIP
@@ -584,8 +586,8 @@ class LCAONet(BaseMPNN):
             from .train import forward_differentiable
 
             return forward_differentiable(self, graph)
-        if precision not in ("fp32", "bf16x3"):
-            raise ValueError(f"precision={precision!r}: expected 'fp32' or 'bf16x3'")
+        if precision not in ("fp32",) + ops.LOWP:
+            raise ValueError(f"precision={precision!r}: expected 'fp32', 'bf16x3' or 'f16'")
         dev = graph[GraphKeys.Pos].device
         if dev.type == "cuda":
             ops.raise_pending_errors(dev)            # an earlier forward that has finished and flagged a bad index
@@ -623,7 +625,7 @@ class LCAONet(BaseMPNN):
         """Eval mode with the fused coefficient kernel on every layer: the coefficient rows are gathered in-kernel."""
         if self.training or fused is False:
             return False
-        if precision == "bf16x3" and (self.add_valence or self.emb_size_coeff != self.emb_size_conv):
+        if precision in ops.LOWP and (self.add_valence or self.emb_size_coeff != self.emb_size_conv):
             return False
         return all(layer._fusable(self.emb_size_coeff) for layer in self.int_layers)
 

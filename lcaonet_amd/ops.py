@@ -339,8 +339,12 @@ def coeff_contract(cstf, rb, order, l_of_d, mask, V, n_l, valence):
     return A, B, Bv
 
 
-def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, src_p=None, cst_row=None):
-    """bf16-MFMA ("bf16x3" split) variant of coeff_mlp_contract; same outputs (no valence)."""
+LOWP = ("bf16x3", "f16")    # precision modes of the 16-bit matrix path (csrc/lcao_lowp.hip)
+
+
+def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, src_p=None, cst_row=None, precision="bf16x3"):
+    """16-bit-MFMA variant of coeff_mlp_contract (precision "bf16x3": split operands, ~1e-5; "f16": one fp16 MFMA per
+    product, ~3e-4); same outputs (no valence)."""
     cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
     E, D = rb.shape
     V, C = W1.shape
@@ -353,7 +357,7 @@ def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, sr
     if gated:
         gate = _f32(gate, "gate")
     ws = torch.empty(2, device=dev, dtype=torch.int32)
-    _call("lcao_coeff_mlp_contract_bf16x3", _p(cst), _p(rb), _p(order), _p(cst_row), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
+    _call("lcao_coeff_mlp_contract_" + precision, _p(cst), _p(rb), _p(order), _p(cst_row), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
           D, C, V, n_l, _p(A), _p(B), _p(Ag), _p(gram), _p(ws), 8, _stream())
     return (Ag if gated else A), gram, B, None
 
@@ -499,7 +503,8 @@ def edge_lcao_weight(tbw, B, W3, Wb, precision="fp32", save=False):
         ft = torch.empty(E, V, device=B.device, dtype=torch.float32)
         _call("lcao_edge_lcao_weight_saving", _p(tbw), _p(B), _p(W3), _p(Wb), E, V, _p(bw), _p(ft), _stream())
         return bw, ft
-    _call("lcao_edge_lcao_weight_bf16x3" if precision == "bf16x3" else "lcao_edge_lcao_weight", _p(tbw), _p(B), _p(W3), _p(Wb), E, V, _p(bw), _stream())
+    _call("lcao_edge_lcao_weight_" + precision if precision in LOWP else "lcao_edge_lcao_weight", _p(tbw), _p(B), _p(W3), _p(Wb), E, V,
+          _p(bw), _stream())
     return bw
 
 
@@ -513,8 +518,8 @@ def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, precision="fp32", save
         _call("lcao_edge_node_message_saving", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V,
               _p(msg), _p(pre2), _stream())
         return msg, pre2
-    _call("lcao_edge_node_message_bf16x3" if precision == "bf16x3" else "lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt), _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg),
-                                          _stream())
+    _call("lcao_edge_node_message_" + precision if precision in LOWP else "lcao_edge_node_message", _p(bw), _p(Ps), _p(Pt),
+          _p(src_p), _p(dst_p), _p(Wn2), _p(bn2), E, V, _p(msg), _stream())
     return msg
 
 

@@ -1082,3 +1082,26 @@ def test_cfg3_bf16x3_vs_oracle(dev, width):
     assert max(e_tbw, e_x, e_out) <= 1e-4          # what the two-term split actually delivers (regression guard)
     e_pair = relerr(m(g.to(dev), precision="bf16x3", cst_mode="pair"), want)   # two-body kernels in bf16x3, pair table
     assert e_pair <= 1e-4
+
+
+@pytest.mark.parametrize("width", [128, 64, 32])
+def test_cfg3_f16_vs_oracle(dev, width):
+    """BASELINE config 3 at its STATED tolerance: one fp16 MFMA per product (operands rounded once to 11 significant bits,
+    fp32 accumulation) on the per-edge GEMMs — <= 1e-3 on every traced tensor at the config's width V = 128 (measured
+    1.7-2.9e-4 here, 8.5e-5 on the 1 M-edge bench batch), against the fp32 oracle."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=64, emb_size_coeff=width, emb_size_conv=width, n_interaction=3, cutoff=5.0, max_z=36)
+    m, sd = _random_model(dev, 500 + width, **kw)
+    g = random_periodic_cells(3, 14, 6.2, 0.99 * 5.0, seed=width + 2)
+    want, wtr = _oracle_run(sd, kw, g.to_dict())
+    tr = {}
+    got = m(g.to(dev), precision="f16", trace=tr)
+    order = tr["order"].long().cpu()
+    e_tbw = relerr(tr["three_body_w1"], wtr["three_body_w1"][order])
+    e_x, e_out = relerr(tr["x3"], wtr["x3"]), relerr(got, want)
+    print(f"f16 V={width}: three_body_w1 {e_tbw:.2e}  x3 {e_x:.2e}  out {e_out:.2e}")
+    # the config (H = C = V = 128) at its stated tolerance; narrower layers average the fp16 rounding (2^-12 per operand)
+    # over fewer terms and the 3-cell energies of this test cancel: 1e-3 is then the noise level itself, bound 3e-3
+    tol = 1e-3 if width == 128 else 3e-3
+    assert max(e_tbw, e_x, e_out) <= tol
+    assert relerr(m(g.to(dev), precision="f16", cst_mode="pair"), want) <= tol
