@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary modes (profiling runs)")
     ap.add_argument("--fused", type=int, default=-1, help="-1 auto, 0 generic kernels only, 1 force fused")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "f16"],
+                    help="NOT for the headline: run the timed loop in a BASELINE config-3 precision mode (profiling)")
     ap.add_argument("--n-side", type=int, default=0, help="cfg4: atoms per crystal edge (0 = 126 at 8 ranks, 250 k atoms per rank otherwise)")
     ap.add_argument("--emulate-world", type=int, default=0, help="cfg4 on ONE GPU: time one rank's slab of a W-way partition")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -339,15 +341,16 @@ def main():
     fused = None if args.fused < 0 else bool(args.fused)
 
     with torch.no_grad():
+        mkw = {} if args.precision == "fp32" else {"precision": args.precision}
         for _ in range(args.warmup):
-            out = model(batch, fused=fused)
+            out = model(batch, fused=fused, **mkw)
         barrier()
         t0 = time.perf_counter()
         # HIP events (torch's current stream = the stream the library launches on) around the two roofline kernels
         # only: bracketing all ~60 calls of a forward costs ~1 ms per step
         with ops.profile(only=ROOFLINE_KERNELS) as prof:
             for _ in range(args.steps):
-                out = model(batch, fused=fused)
+                out = model(batch, fused=fused, **mkw)
             barrier()
             elapsed = time.perf_counter() - t0
             ksum = prof.summary()
@@ -371,15 +374,19 @@ def main():
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t1) / args.steps, err
 
-    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = mat_ms = mat_err = h_ms = h_err = None
     secondary_error = None
+    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = mat_ms = mat_err = h_ms = h_err = None
     kall = {}
-    if rank == 0 and not args.no_secondary:
+    if rank == 0:
         try:
             with torch.no_grad(), ops.profile() as prof_all:                 # per-entry-point breakdown, separate pass
                 for _ in range(args.steps):
-                    model(batch, fused=fused)
+                    model(batch, fused=fused, **mkw)
                 kall = prof_all.summary()
+        except Exception as e:  # noqa: BLE001
+            secondary_error = f"{type(e).__name__}: {e}"
+    if rank == 0 and not args.no_secondary and args.precision == "fp32":
+        try:
             if not with_forces:   # the force workloads already run on the pair table; no secondary modes there
                 mat_ms, mat_err = timed(cst_mode="edge_tensor")              # cst materialised per edge as the reference holds it
                 pair_ms, pair_err = timed(cst_mode="pair")                   # species-pair table
@@ -479,7 +486,7 @@ def main():
             "metric": "edges/sec forward (LCAOConv stack), 1M-edge synthetic batch",
             "value": e_total * args.steps / elapsed_max, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32"}.get(args.precision, args.precision), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {shape} per GPU (N={N}, E={E} per GPU), graph cutoff "
                                    f"{gen_kw['cutoff_graph']}, "
                                    f"LCAONet(emb_size={model.emb_size}, coeff={C}, conv={V}, n_interaction={L}, D={D}, "
