@@ -1306,10 +1306,18 @@ extern "C" int lcao_triplet_gemm(const float* Ag, const float* gram, const float
   int64_t groups = (n_nodes + 3) / 4;
   int64_t cap = (int64_t)lcao_num_cu() * 8;
   if (groups > cap) groups = cap;
+  // occupancy experiment (tools/k3_ablate.py): LCAO_K3_LDS = bytes of unused dynamic LDS per workgroup caps the waves/SIMD
+  static int k3_lds = -1;
+  if (k3_lds < 0) { const char* e_ = getenv("LCAO_K3_LDS"); k3_lds = e_ ? atoi(e_) : 0; }
 #define TG_CASE(V_, NL_)                                                                                          \
   if (V == V_ && n_l == NL_) {                                                                                    \
-    hipLaunchKernelGGL((k_triplet_gemm<V_, NL_>), dim3((unsigned)groups), dim3(256), 0, st, Ag, gram, uvec_p, in_ptr, \
-                       in_pos, out_ptr, (int)n_nodes, tbw);                                                       \
+    if (k3_lds > 48 * 1024) {                                                                                     \
+      static bool done_ = false;                                                                                  \
+      int rc_ = set_lds_attr(k_triplet_gemm<V_, NL_>, (size_t)k3_lds, done_);                                     \
+      if (rc_ != LCAO_OK) return rc_;                                                                             \
+    }                                                                                                             \
+    hipLaunchKernelGGL((k_triplet_gemm<V_, NL_>), dim3((unsigned)groups), dim3(256), (size_t)k3_lds, st, Ag, gram, uvec_p, \
+                       in_ptr, in_pos, out_ptr, (int)n_nodes, tbw);                                               \
     return lcao_launch_status();                                                                                  \
   }
 #define TG_V(V_) TG_CASE(V_, 1) TG_CASE(V_, 2) TG_CASE(V_, 3) TG_CASE(V_, 4)
