@@ -198,3 +198,44 @@ def test_basis_options_vs_reference_tables(golden_loader, dev):
             noise = relerr(ref[:, d], ref64[:, d])
             assert relerr(rb[:, d], ref[:, d]) <= max(TOL, 1.02 * noise), (p, d, relerr(rb[:, d], ref[:, d]), noise)
             assert relerr(rb[:, d], ref64[:, d]) <= max(0.5 * noise, 1e-6), (p, d)
+
+
+def _sweep_cases():
+    import random
+    rnd = random.Random(20261004)
+    cases = []
+    for i in range(24):
+        V = rnd.choice([16, 24, 32, 48, 64, 96, 128])
+        C = rnd.choice([V, V, 32, 64, 128])
+        H = rnd.choice([16, 40, 64, 128, 256])
+        kw = dict(emb_size=H, emb_size_coeff=C, emb_size_conv=V, n_interaction=rnd.choice([1, 2, 3]),
+                  cutoff=rnd.choice([4.0, 5.0]), max_z=rnd.choice([10, 36, 84]), add_valence=rnd.random() < 0.3,
+                  n_per_orb=rnd.choice([1, 1, 2]), cutoff_net=rnd.choice(["envelope", "polynomial", "cosine"]),
+                  rbf_type=rnd.choice(["hydrogen", "hydrogen", "sphericalbessel"]), elec_to_node=rnd.random() < 0.8,
+                  is_extensive=rnd.random() < 0.7, out_size=rnd.choice([1, 2]), extend_orb=rnd.random() < 0.2)
+        cases.append((i, kw, rnd.choice(["cells", "cells", "molecules"])))
+    return cases
+
+
+@pytest.mark.parametrize("idx,kw,kind", _sweep_cases())
+def test_random_configuration_sweep_vs_oracle(dev, idx, kw, kind):
+    """24 seeded random constructor / width / graph combinations (fused and unfused kernel paths, node tables with and
+    without the folded launch, in-kernel coefficient-row gather, fused scatter, valence, n_per_orb, all cutoffs and bases),
+    default forward and cst_mode='pair' against the oracle at 1e-5."""
+    from lcaonet_amd.data.synthetic import random_molecule_batch, random_periodic_cells
+    m, sd = _random_model(dev, 9000 + idx, **kw)
+    if kind == "cells":
+        g = random_periodic_cells(3, 10 + idx % 5, 6.0, 0.99 * kw["cutoff"], seed=idx, max_z=kw["max_z"]).to(dev)
+    else:
+        species = (1, 6, 7, 8, 9) if kw["max_z"] >= 9 else (1, 2)
+        g = random_molecule_batch(5, 3, 9, cutoff_graph=0.99 * kw["cutoff"], seed=idx, species=species, device=dev)
+    gc = {k: v.cpu() for k, v in g.to_dict().items() if k in ("z", "pos", "edge_index", "edge_shift", "lattice", "batch")}
+    want, wtr = _oracle_run(sd, kw, gc)
+    tr = {}
+    got = m(g, trace=tr)
+    L = kw["n_interaction"]
+    assert relerr(tr[f"x{L}"], wtr[f"x{L}"]) <= TOL, (kw, relerr(tr[f"x{L}"], wtr[f"x{L}"]))
+    assert relerr(got, want) <= TOL, (kw, relerr(got, want))
+    with torch.no_grad():
+        assert relerr(m(g), want) <= TOL                       # no trace: the fully fused route
+        assert relerr(m(g, cst_mode="pair"), want) <= TOL

@@ -211,3 +211,50 @@ def test_sharded_training_matches_single_process(dev, training):
             assert relerr(grads[n], p.grad) <= 2e-4, (n, relerr(grads[n], p.grad))
             checked += 1
         assert checked > 25
+
+
+def _grad_sweep_cases():
+    import random
+    rnd = random.Random(777)
+    cases = []
+    for i in range(10):
+        V = rnd.choice([16, 24, 32, 48, 64, 128])
+        kw = dict(emb_size=rnd.choice([16, 32, 64]), emb_size_coeff=rnd.choice([V, 32]), emb_size_conv=V,
+                  n_interaction=rnd.choice([1, 2]), cutoff=4.5, max_z=rnd.choice([10, 36]), add_valence=rnd.random() < 0.3,
+                  n_per_orb=rnd.choice([1, 2]), cutoff_net=rnd.choice(["envelope", "polynomial", "cosine"]),
+                  rbf_type=rnd.choice(["hydrogen", "sphericalbessel"]), is_extensive=rnd.random() < 0.7,
+                  activation=rnd.choice(["SiLU", "SiLU", "Tanh", "ShiftedSoftplus"]))
+        cases.append((i, kw, rnd.random() < 0.5, rnd.random() < 0.5))
+    return cases
+
+
+@pytest.mark.parametrize("idx,kw,training,forces", _grad_sweep_cases())
+def test_random_configuration_gradient_sweep(dev, idx, kw, training, forces):
+    """Seeded random configurations through the differentiable paths — the fused training sweep (SiLU) or the generic
+    twice-differentiable graph (other activations), with and without a force term in the loss (exact double backward) —
+    every parameter gradient against torch.autograd through the fp64 oracle."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(kw)
+    if forces:
+        kw.update(regress_forces=True, direct_forces=False)
+    m, sd = _random_model(dev, 6000 + idx, grad=True, **kw)
+    m.train(training)
+    g = random_periodic_cells(2, 9, 6.0, 0.99 * 4.5, seed=50 + idx, max_z=kw["max_z"])
+    okw = {k: v for k, v in kw.items() if k != "activation"}
+    cfg = _ocfg({**okw, "rbf_type": kw["rbf_type"], "training": training, "extra": {"activation": kw["activation"]}})
+    sdg = {k: (v.clone().double().requires_grad_("running_" not in k) if v.is_floating_point() else v.clone())
+           for k, v in sd.items()}
+    ref = O.forward(sdg, cfg, g.to_dict(), dtype=torch.float64)
+    out = m(g.to(dev))
+    if forces:
+        (e_ref, f_ref), (e, f) = ref, out
+        assert relerr(e.detach(), e_ref.detach()) <= 2e-5 and relerr(f.detach(), f_ref.detach()) <= 5 * TOL
+        ((e_ref ** 2).mean() + (f_ref ** 2).mean()).backward()
+        ((e ** 2).mean() + (f ** 2).mean()).backward()
+    else:
+        assert relerr(out.detach(), ref.detach()) <= 2e-5
+        (ref ** 2).mean().backward()
+        (out ** 2).mean().backward()
+    want = {k: v.grad for k, v in sdg.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
+    checked, worst = _check_param_grads(m, want, 2e-4)
+    assert checked > 15, checked
