@@ -346,6 +346,13 @@ int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* dst_p, const
 int lcao_trip_sddmm(const float* G, const float* A, const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos,
                     const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int V, int n_l, float* out, void* stream);
 
+/* The per-edge Gram matrix of lcaonet.py:179-184 (|sum_l Y_l A[q,l,:]|^2 = Y^T G_q Y, G_q = A_q A_q^T) as a second closed
+ * family:  rowgram: out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]   (E, n_l, n_l)
+ *          rowmix : out[e,l,v] = sum_m S[e,l,m] A[e,m,v]   (E, n_l, V); trans != 0 reads S[e,m,l]
+ * (d rowgram = rowmix of the other operand, d rowmix = rowgram / rowmix with S transposed).  Any V <= 512. */
+int lcao_rowgram(const float* X, const float* Y, int64_t n_edges, int V, int n_l, float* out, void* stream);
+int lcao_rowmix(const float* S, const float* A, int64_t n_edges, int V, int n_l, int trans, float* out, void* stream);
+
 size_t lcao_lds_bytes_coeff_mlp(int C, int V, int valence);
 
 /* Diagnostics only (tools/clock_probe.py): buffer of 2 x uint64 per wave of lcao_coeff_mlp_contract receiving

@@ -132,6 +132,85 @@ __global__ void k_trip_sddmm(const float* __restrict__ G, const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The per-edge Gram matrix G[e] = A[e] A[e]^T (n_l x n_l, lcaonet.py:179-184 in Gram form) as a second closed family:
+//     rowgram(X, Y) -> out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]
+//     rowmix (S, A) -> out[e,l,v] = sum_m S[e,l,m] A[e,m,v]          (or S[e,m,l]: `trans`)
+// d rowgram/dX = rowmix(g, Y), d rowgram/dY = rowmix(g^T, X);  d rowmix/dS = rowgram(g, A) (or rowgram(A, g)),
+// d rowmix/dA = rowmix(S^T, g).  One wave per edge, lanes over channels; both stream their operands once (HBM-bound).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int R, int NLMAX>
+__global__ void k_rowgram(const float* __restrict__ X, const float* __restrict__ Y, int64_t n_edges, int V, int NL,
+                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; e < n_edges; e += nwave) {
+    float x[NLMAX][R], y[NLMAX][R];
+#pragma unroll
+    for (int l = 0; l < NLMAX; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ch = lane + 64 * r;
+        const bool ok = l < NL && ch < V;
+        x[l][r] = ok ? X[(e * NL + l) * V + ch] : 0.f;
+        y[l][r] = ok ? Y[(e * NL + l) * V + ch] : 0.f;
+      }
+    // 16 partial dot products per lane -> row sums by DPP -> lane (row k, r) keeps product r -> two cross-row steps
+    float mine = 0.f;
+#pragma unroll
+    for (int l = 0; l < NLMAX; ++l)
+#pragma unroll
+      for (int m = 0; m < NLMAX; ++m) {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) d += x[l][r] * y[m][r];
+        d = lcao_row16_sum(d);
+        if ((lane & 15) == l * NLMAX + m) mine = d;
+      }
+    mine += __shfl_xor(mine, 16);
+    mine += __shfl_xor(mine, 32);
+    const int l = (lane & 15) / NLMAX, m = (lane & 15) % NLMAX;
+    if (lane < 16 && l < NL && m < NL) out[(e * NL + l) * NL + m] = mine;
+  }
+}
+
+template <int R, int NLMAX>
+__global__ void k_rowmix(const float* __restrict__ S, const float* __restrict__ A, int64_t n_edges, int V, int NL,
+                         int trans, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; e < n_edges; e += nwave) {
+    float a[NLMAX][R];
+#pragma unroll
+    for (int m = 0; m < NLMAX; ++m)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ch = lane + 64 * r;
+        a[m][r] = (m < NL && ch < V) ? A[(e * NL + m) * V + ch] : 0.f;
+      }
+    const float* s = S + e * NL * NL;
+#pragma unroll
+    for (int l = 0; l < NLMAX; ++l)
+      if (l < NL) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < NLMAX; ++m)
+          if (m < NL) {
+            const float sv = trans ? s[m * NL + l] : s[l * NL + m];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] += sv * a[m][r];
+          }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          if (ch < V) out[(e * NL + l) * V + ch] = acc[r];
+        }
+      }
+  }
+}
+
 static int check_trip(int64_t n_edges, int V, int n_l) {
   if (n_edges < 0 || n_edges >= (int64_t(1) << 31)) return LCAO_ERR_INVALID;
   if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
@@ -195,5 +274,40 @@ extern "C" int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* d
   else if (R_ <= 4) TT(4);
   else TT(8);
 #undef TT
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_rowgram(const float* X, const float* Y, int64_t n_edges, int V, int n_l, float* out, void* stream) {
+  int rc = check_trip(n_edges, V, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(X); LCAO_CHECK_PTR(Y); LCAO_CHECK_PTR(out);
+  hipStream_t st = (hipStream_t)stream;
+  const int R_ = (V + 63) / 64;
+  dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
+#define GG(RR) hipLaunchKernelGGL((k_rowgram<RR, 4>), grid, block, 0, st, X, Y, n_edges, V, n_l, out)
+  if (R_ == 1) GG(1);
+  else if (R_ == 2) GG(2);
+  else if (R_ <= 4) GG(4);
+  else GG(8);
+#undef GG
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_rowmix(const float* S, const float* A, int64_t n_edges, int V, int n_l, int trans, float* out,
+                           void* stream) {
+  int rc = check_trip(n_edges, V, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(S); LCAO_CHECK_PTR(A); LCAO_CHECK_PTR(out);
+  hipStream_t st = (hipStream_t)stream;
+  const int R_ = (V + 63) / 64;
+  dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
+#define MM(RR) hipLaunchKernelGGL((k_rowmix<RR, 4>), grid, block, 0, st, S, A, n_edges, V, n_l, trans, out)
+  if (R_ == 1) MM(1);
+  else if (R_ == 2) MM(2);
+  else if (R_ <= 4) MM(4);
+  else MM(8);
+#undef MM
   return lcao_launch_status();
 }

@@ -718,6 +718,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
     f32x4v o[MT], wv[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) wv[m] = *(const f32x4v*)(bw + pw * V + 16 * m + 4 * q);  // in flight under the GEMM
+    const int eb = out_ptr[s_cur], ee = out_ptr[s_cur + 1];   // first / one-past-last edge of this lane's centre node
 #pragma unroll
     for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
     __builtin_amdgcn_s_setprio(1);
@@ -727,15 +728,25 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[m][j] = valid ? wv[m][j] * lcao_silu(o[m][j]) : 0.f;   // message rows; 0 past the chunk
-    // segmented sum over the 16 edges of the tile, node by node (wave-uniform loop; 1-3 nodes per tile)
-    const int s_first = __builtin_amdgcn_readfirstlane(s_cur);
-    const int s_last = __builtin_amdgcn_readlane(s_cur, min(15, pend - pb - 1));
-    for (int node = s_first; node <= s_last; ++node) {
-      const int e_beg = out_ptr[node], e_end = out_ptr[node + 1];
-      if (e_end == e_beg) continue;
-      const bool mine = s_cur == node;          // (invalid lanes hold zeros already)
-      const bool fresh = e_beg >= pb;           // the node's first edge lies in this tile: no carry to add
-      const bool done = e_end <= pb + 16;       // ... and its last one too: the row is complete
+    // segmented sum over the 16 edges of the tile, segment by segment (wave-uniform loop over the segment heads found by
+    // a ballot; 1-3 per tile).  Only the first segment can continue a node from the previous tile and only the last can
+    // continue into the next: their node bounds come from two vector loads issued before the GEMM (eb / ee), so the
+    // loop itself touches no memory.
+    const int s_prev = __shfl_up(s_cur, 1);                                        // (all lanes active: outside the ?:)
+    const unsigned long long heads =
+        __ballot(valid & ((r == 0) | (s_cur != s_prev))) & 0xFFFFull;              // bit r: edge r opens a segment (row 0)
+    const int n_valid = min(16, pend - pb);
+    const int first_beg = __builtin_amdgcn_readfirstlane(eb);
+    const int last_end = __builtin_amdgcn_readlane(ee, n_valid - 1);
+    unsigned rem = (unsigned)heads;
+    while (rem) {
+      const int a = __builtin_ctz(rem);
+      rem &= rem - 1;
+      const int b = rem ? __builtin_ctz(rem) : n_valid;           // segment = lanes [a, b)
+      const bool mine = r >= a && r < b;                          // (lanes past n_valid hold zeros already)
+      const bool fresh = a > 0 || first_beg >= pb;                // the node's first edge lies in this tile: no carry
+      const bool done = rem != 0 || last_end <= pb + 16;          // ... and its last one too: the row is complete
+      const int node = __builtin_amdgcn_readlane(s_cur, a);
       float* out = agg + (int64_t)node * V + 4 * q;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {

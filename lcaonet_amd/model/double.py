@@ -336,6 +336,45 @@ class _SddmmFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# per-edge Gram matrices (csrc/lcao_double.hip: rowgram / rowmix, closed under differentiation)
+# ---------------------------------------------------------------------------------------------------------------------
+class _RowGramFn(Function):
+    @staticmethod
+    def forward(ctx, X, Y):
+        ctx.save_for_backward(X, Y)
+        return ops.rowgram(X, Y)
+
+    @staticmethod
+    def backward(ctx, g):
+        X, Y = ctx.saved_tensors
+        g = g.contiguous()
+        return (_RowMixFn.apply(g, Y, False) if ctx.needs_input_grad[0] else None,
+                _RowMixFn.apply(g, X, True) if ctx.needs_input_grad[1] else None)
+
+
+class _RowMixFn(Function):
+    @staticmethod
+    def forward(ctx, S, A, trans):
+        ctx.trans = trans
+        ctx.save_for_backward(S, A)
+        return ops.rowmix(S, A, trans)
+
+    @staticmethod
+    def backward(ctx, g):
+        S, A = ctx.saved_tensors
+        g = g.contiguous()
+        gS = None
+        if ctx.needs_input_grad[0]:
+            gS = _RowGramFn.apply(A, g) if ctx.trans else _RowGramFn.apply(g, A)
+        return gS, (_RowMixFn.apply(S, g, not ctx.trans) if ctx.needs_input_grad[1] else None), None
+
+
+def rowgram(X: Tensor, Y: Tensor) -> Tensor:
+    """out[e,l,m] = X[e,l,:] . Y[e,m,:]  (twice differentiable)."""
+    return _RowGramFn.apply(X.contiguous(), Y.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # the energy as a function of positions and parameters
 # ---------------------------------------------------------------------------------------------------------------------
 def _mlp(seq, x: Tensor) -> Tensor:
@@ -353,7 +392,7 @@ def _triplet_weights(geo: _Geo, u: Tensor, G: Tensor) -> Tensor:
     ys = [torch.full_like(c, Y0), Y1 * c, Y2A * c * c - Y2B, Y3 * c * (5.0 * c * c - 3.0)][:n_l]
     y = torch.stack(ys, dim=1)                                               # (T, n_l)
     Gq = gather(G.reshape(geo.E, n_l * n_l), geo.tq).reshape(-1, n_l, n_l)
-    n2 = torch.einsum("tl,tlm,tm->t", y, Gq, y)
+    n2 = ((Gq * y.unsqueeze(1)).sum(dim=2) * y).sum(dim=1)                    # y^T G_q y (no batched-GEMM call)
     inv = torch.rsqrt(torch.clamp_min(n2, 1e-24))
     return y * inv.unsqueeze(1) * geo.tmask
 
@@ -395,7 +434,7 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
             A = _ContractFn.apply(rb, Tf, geo)
             B, Bv = A.sum(dim=1), None
         Ag = A * gather(gate, geo.src).unsqueeze(1)
-        G = torch.einsum("elv,emv->elm", A, A)
+        G = rowgram(A, A)
         tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)               # (e_own, V)
         ft = dense(tbw, layer.f_three[0].weight)
         B = B[: geo.e_own]

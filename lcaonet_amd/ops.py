@@ -705,3 +705,25 @@ def trip_sddmm(G, A, geo):
     _call("lcao_trip_sddmm", _p(G), _p(A), _p(c.src_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), E, V, n_l,
           _p(out), _stream())
     return out
+
+
+def rowgram(X, Y):
+    """out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]  — per-edge Gram matrices (E, n_l, n_l)."""
+    X, Y = _f32(X, "X"), _f32(Y, "Y")
+    if X.shape != Y.shape or X.dim() != 3:
+        raise ValueError(f"rowgram: X {tuple(X.shape)} and Y {tuple(Y.shape)} must both be (E, n_l, V)")
+    E, n_l, V = X.shape
+    out = torch.empty(E, n_l, n_l, device=X.device, dtype=torch.float32)
+    _call("lcao_rowgram", _p(X), _p(Y), E, V, n_l, _p(out), _stream())
+    return out
+
+
+def rowmix(S, A, trans: bool = False):
+    """out[e,l,v] = sum_m S[e,l,m] A[e,m,v]   (S[e,m,l] with trans)."""
+    S, A = _f32(S, "S"), _f32(A, "A")
+    E, n_l, V = A.shape
+    if tuple(S.shape) != (E, n_l, n_l):
+        raise ValueError(f"rowmix: S {tuple(S.shape)} must be ({E}, {n_l}, {n_l})")
+    out = torch.empty(E, n_l, V, device=A.device, dtype=torch.float32)
+    _call("lcao_rowmix", _p(S), _p(A), E, V, n_l, int(bool(trans)), _p(out), _stream())
+    return out

@@ -149,6 +149,38 @@ def test_trip_bilinear_family_is_consistent(dev):
         assert relerr(ops.trip_sddmm(G, A, geo), want_d) <= 2e-6
 
 
+def test_rowgram_family_first_and_second_derivatives(dev):
+    """csrc/lcao_double.hip rowgram / rowmix (the per-edge Gram matrix of lcaonet.py:179-184 and its derivatives): values
+    against fp64 einsums, and gradient + gradient-of-gradient through model/double.py's Functions against autograd of
+    the same einsum."""
+    from lcaonet_amd import ops
+    from lcaonet_amd.model.double import rowgram
+    for E, n_l, V in ((1, 1, 16), (37, 3, 48), (501, 4, 128), (64, 2, 200), (9, 4, 512)):
+        gen = torch.Generator(device="cpu").manual_seed(E + V)
+        X = torch.randn(E, n_l, V, generator=gen).to(dev)
+        Y = torch.randn(E, n_l, V, generator=gen).to(dev)
+        S = torch.randn(E, n_l, n_l, generator=gen).to(dev)
+        assert relerr(ops.rowgram(X, Y), torch.einsum("elv,emv->elm", X.double(), Y.double())) <= 2e-6
+        assert relerr(ops.rowmix(S, X), torch.einsum("elm,emv->elv", S.double(), X.double())) <= 2e-6
+        assert relerr(ops.rowmix(S, X, True), torch.einsum("eml,emv->elv", S.double(), X.double())) <= 2e-6
+        # scalar f(A) = sum(c * tanh(G(A))) with G = A A^T;  compare df/dA and d/dA <df/dA, R> with the fp64 einsum graph
+        A = (0.3 * X).requires_grad_(True)
+        A64 = (0.3 * X).double().requires_grad_(True)
+        c, R = S, Y
+
+        def chain(A_, gram, c_, R_):
+            f = (c_ * torch.tanh(gram(A_))).sum()
+            (g1,) = torch.autograd.grad(f, A_, create_graph=True)
+            (g2,) = torch.autograd.grad((g1 * R_).sum(), A_)
+            return g1.detach(), g2
+        g1, g2 = chain(A, lambda a: rowgram(a, a), c, R)
+        w1, w2 = chain(A64, lambda a: torch.einsum("elv,emv->elm", a, a), c.double(), R.double())
+        assert relerr(g1, w1) <= 5e-6 and relerr(g2, w2) <= 5e-6
+    assert ops.rowgram(torch.zeros(0, 4, 32, device=dev), torch.zeros(0, 4, 32, device=dev)).shape == (0, 4, 4)
+    with pytest.raises(ValueError):
+        ops.rowmix(torch.zeros(3, 2, 2, device=dev), torch.zeros(3, 4, 32, device=dev))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # single-graph TRAINING over ranks (BatchNorm statistics of the whole graph, autograd-aware halo exchange)
 # ---------------------------------------------------------------------------------------------------------------------
