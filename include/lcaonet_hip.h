@@ -337,14 +337,19 @@ int lcao_geometry_bwd(const float* dist, const float* uvec, const float* g_rb, c
  *   sddmm : out[t,l]   = G[p,:] . A[q,l,:]                                          (T, n_l)
  * a bilinear family closed under differentiation (each op's two derivatives are the other two), so autograd can
  * differentiate the backward pass again.  Triplet slot t(p,q) = tbase[s] + rank_out(p) * m_in(s) + rank_in(q) with
- * s = src(p) = dst(q); in_rank[q] = rank of q in its node's in-list.  Any V <= 512; deterministic. */
+ * s = src(p) = dst(q); in_rank[q] = rank of q in its node's in-list; n_centres = number of nodes that own out-edges
+ * here (all of them, or the owned nodes of a sharded graph; n_edges counts their out-edges for spmm / sddmm and every
+ * local edge for spmm_t, whose rows of non-centre targets are zero).  Any V <= 512 (one wave per centre node on fp32
+ * MFMA tiles when V % 4 == 0); deterministic. */
 int lcao_trip_spmm(const float* w, const float* A, const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos,
-                   const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int V, int n_l, float* out, void* stream);
+                   const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int V, int n_l,
+                   float* out, void* stream);
 int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* dst_p, const int32_t* in_rank, const int32_t* in_ptr,
-                     const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int V, int n_l,
-                     float* out, void* stream);
+                     const int32_t* in_pos, const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges,
+                     int64_t n_centres, int V, int n_l, float* out, void* stream);
 int lcao_trip_sddmm(const float* G, const float* A, const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos,
-                    const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int V, int n_l, float* out, void* stream);
+                    const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int V, int n_l,
+                    float* out, void* stream);
 
 /* The per-edge Gram matrix of lcaonet.py:179-184 (|sum_l Y_l A[q,l,:]|^2 = Y^T G_q Y, G_q = A_q A_q^T) as a second closed
  * family:  rowgram: out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]   (E, n_l, n_l)

@@ -70,9 +70,9 @@ SIGNATURES = {
     "lcao_pair_contract_bwd": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, P, P, P, P],
     "lcao_pair_table_grad": [P, P, P, P, P, P, L, I, I, I, P, P],
     "lcao_geometry_bwd": [P, P, P, P, L, I, P, I, I, F, P, P],
-    "lcao_trip_spmm": [P, P, P, P, P, P, P, L, I, I, P, P],
-    "lcao_trip_spmm_t": [P, P, P, P, P, P, P, L, L, I, I, P, P],
-    "lcao_trip_sddmm": [P, P, P, P, P, P, P, L, I, I, P, P],
+    "lcao_trip_spmm": [P, P, P, P, P, P, P, L, L, I, I, P, P],
+    "lcao_trip_spmm_t": [P, P, P, P, P, P, P, P, L, L, I, I, P, P],
+    "lcao_trip_sddmm": [P, P, P, P, P, P, P, L, L, I, I, P, P],
     "lcao_rowgram": [P, P, L, I, I, P, P],
     "lcao_rowmix": [P, P, L, I, I, I, P, P],
     "lcao_lds_bytes_coeff_mlp": [I, I, I],

@@ -679,8 +679,8 @@ def trip_spmm(w, A, geo):
     _, n_l, V = A.shape
     c, E = geo.ctx, geo.e_own
     out = torch.empty(E, V, device=A.device, dtype=torch.float32)
-    _call("lcao_trip_spmm", _p(w), _p(A), _p(c.src_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), E, V, n_l,
-          _p(out), _stream())
+    _call("lcao_trip_spmm", _p(w), _p(A), _p(c.src_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), E,
+          geo.n_own, V, n_l, _p(out), _stream())
     return out
 
 
@@ -691,8 +691,8 @@ def trip_spmm_t(w, G, geo):
     n_l = w.shape[1]
     c, E = geo.ctx, geo.E
     out = torch.empty(E, n_l, V, device=G.device, dtype=torch.float32)
-    _call("lcao_trip_spmm_t", _p(w), _p(G), _p(c.dst_p), _p(geo.in_rank), _p(c.in_ptr), _p(c.out_ptr), _p(geo.tbase), E,
-          geo.n_own, V, n_l, _p(out), _stream())
+    _call("lcao_trip_spmm_t", _p(w), _p(G), _p(c.dst_p), _p(geo.in_rank), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr),
+          _p(geo.tbase), E, geo.n_own, V, n_l, _p(out), _stream())
     return out
 
 
@@ -702,8 +702,8 @@ def trip_sddmm(G, A, geo):
     _, n_l, V = A.shape
     c, E = geo.ctx, geo.e_own
     out = torch.zeros(geo.T, n_l, device=A.device, dtype=torch.float32)
-    _call("lcao_trip_sddmm", _p(G), _p(A), _p(c.src_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), E, V, n_l,
-          _p(out), _stream())
+    _call("lcao_trip_sddmm", _p(G), _p(A), _p(c.src_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), E,
+          geo.n_own, V, n_l, _p(out), _stream())
     return out
 
 

@@ -129,7 +129,7 @@ def test_trip_bilinear_family_is_consistent(dev):
     from lcaonet_amd.model import LCAONet
     from lcaonet_amd.model.double import _Geo
     g = random_periodic_cells(2, 12, 6.0, 0.99 * 4.5, seed=3).to(dev)
-    for V, n_l, max_z in ((48, 3, 36), (128, 2, 10), (200, 4, 96)):
+    for V, n_l, max_z in ((48, 3, 36), (128, 2, 10), (200, 4, 96), (128, 4, 36), (50, 3, 36), (32, 1, 36)):
         m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=V, n_interaction=1, cutoff=4.5, max_z=max(max_z, 36)).to(dev)
         geo = _Geo(m, g)
         geo.n_l = n_l

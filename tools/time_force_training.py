@@ -66,6 +66,9 @@ def main():
             step()
             torch.cuda.synchronize()
         rows = []
+        res["device_ms_total"] = round(sum(getattr(ev, "self_device_time_total", 0) for ev in p.key_averages()) / 1e3, 2)
+        res["kernel_launches"] = sum(ev.count for ev in p.key_averages()
+                                     if getattr(ev, "self_device_time_total", 0) and not ev.cpu_time_total)
         for ev in p.key_averages():
             t = getattr(ev, "device_time_total", None) or getattr(ev, "cuda_time_total", 0)
             if t:
