@@ -351,6 +351,21 @@ int lcao_trip_sddmm(const float* G, const float* A, const int32_t* src_p, const 
                     const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int V, int n_l,
                     float* out, void* stream);
 
+/* The per-triplet weights themselves, w[t,l] = [p != q] Y_l(c_t) / sqrt(max(Y^T G_q Y, 1e-24)) with c_t = u_p . u_q
+ * (lcaonet.py:175-184 in Gram form; c (T), G (E, n_l, n_l), w (T, n_l)), their reverse sweep (gw -> gc, gG) and the
+ * reverse sweep of THAT map for cotangents (hc, hG): ggw = J h, (gc2, gG2) = Hessian-vector product — the three
+ * launches behind the exact double backward.  One thread per in-list position; deterministic, no atomics. */
+int lcao_trip_weight(const float* c, const float* G, const int32_t* dst_p, const int32_t* in_ptr, const int32_t* in_pos,
+                     const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int n_l, float* w,
+                     void* stream);
+int lcao_trip_weight_bwd(const float* gw, const float* c, const float* G, const int32_t* dst_p, const int32_t* in_ptr,
+                         const int32_t* in_pos, const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges,
+                         int64_t n_centres, int n_l, float* gc, float* gG, void* stream);
+int lcao_trip_weight_bwd2(const float* hc, const float* hG, const float* gw, const float* c, const float* G,
+                          const int32_t* dst_p, const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr,
+                          const int64_t* tbase, int64_t n_edges, int64_t n_centres, int n_l, float* ggw, float* gc2,
+                          float* gG2, void* stream);
+
 /* The per-edge Gram matrix of lcaonet.py:179-184 (|sum_l Y_l A[q,l,:]|^2 = Y^T G_q Y, G_q = A_q A_q^T) as a second closed
  * family:  rowgram: out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]   (E, n_l, n_l)
  *          rowmix : out[e,l,v] = sum_m S[e,l,m] A[e,m,v]   (E, n_l, V); trans != 0 reads S[e,m,l]

@@ -73,6 +73,9 @@ SIGNATURES = {
     "lcao_trip_spmm": [P, P, P, P, P, P, P, L, L, I, I, P, P],
     "lcao_trip_spmm_t": [P, P, P, P, P, P, P, P, L, L, I, I, P, P],
     "lcao_trip_sddmm": [P, P, P, P, P, P, P, L, L, I, I, P, P],
+    "lcao_trip_weight": [P, P, P, P, P, P, P, L, L, I, P, P],
+    "lcao_trip_weight_bwd": [P, P, P, P, P, P, P, P, L, L, I, P, P, P],
+    "lcao_trip_weight_bwd2": [P, P, P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],
     "lcao_rowgram": [P, P, L, I, I, P, P],
     "lcao_rowmix": [P, P, L, I, I, I, P, P],
     "lcao_lds_bytes_coeff_mlp": [I, I, I],

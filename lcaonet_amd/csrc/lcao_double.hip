@@ -398,6 +398,176 @@ __global__ void k_rowmix(const float* __restrict__ S, const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The per-triplet weights of lcaonet.py:179-184 in Gram form, as a function of c[t] = u_p . u_q (T) and G (E, n_l, n_l):
+//     w[t, l] = [p != q] Y_l(c_t) / sqrt(max(Y(c_t)^T G_q Y(c_t), 1e-24))
+// with its first derivative (gw -> gc, gG) and the derivative of that map (the second-order terms of force training).
+// One thread per in-list position (node s, in-edge q = in_pos[in_ptr[s] + j]) walks the node's out-edges i: slots
+// tbase[s] + i m_in + j are consecutive across the threads of a node (coalesced), G_q stays in registers and the sum over
+// i that gG needs is a register accumulation — no atomics, fixed order.  The second-order kernel runs the hand-written
+// reverse sweep on dual numbers (value + directional derivative): its tangent is the Hessian-vector product.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TwDual {
+  float v, d;
+  __device__ TwDual() {}
+  __device__ TwDual(float a) : v(a), d(0.f) {}
+  __device__ TwDual(float a, float b) : v(a), d(b) {}
+};
+__device__ __forceinline__ TwDual operator+(TwDual a, TwDual b) { return TwDual(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ TwDual operator-(TwDual a, TwDual b) { return TwDual(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ TwDual operator*(TwDual a, TwDual b) { return TwDual(a.v * b.v, a.v * b.d + a.d * b.v); }
+__device__ __forceinline__ TwDual operator*(float a, TwDual b) { return TwDual(a * b.v, a * b.d); }
+__device__ __forceinline__ TwDual operator-(TwDual a, float b) { return TwDual(a.v - b, a.d); }
+__device__ __forceinline__ float tw_value(float a) { return a; }
+__device__ __forceinline__ float tw_value(TwDual a) { return a.v; }
+__device__ __forceinline__ float tw_rsqrt(float a) { return 1.0f / sqrtf(a); }
+__device__ __forceinline__ TwDual tw_rsqrt(TwDual a) {
+  const float r = 1.0f / sqrtf(a.v);
+  return TwDual(r, -0.5f * r * r * r * a.d);
+}
+
+#define TW_Y0 0.28209479177387814f
+#define TW_Y1 0.48860251190292f
+#define TW_Y2A 0.94617469575756f
+#define TW_Y2B 0.31539156525252f
+#define TW_Y3 0.373176332590115f
+
+// y_l(c), 1/|.| and whether the clamp is inactive
+template <class S, int NL>
+__device__ __forceinline__ void tw_eval(S c, const S* G, S* y, S& inv, bool& live) {
+  y[0] = S(TW_Y0);
+  if (NL > 1) y[1] = TW_Y1 * c;
+  if (NL > 2) y[2] = TW_Y2A * (c * c) - TW_Y2B;
+  if (NL > 3) y[3] = TW_Y3 * (c * (5.0f * (c * c) - 3.0f));
+  S n2 = S(0.f);
+#pragma unroll
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int m = 0; m < NL; ++m) n2 = n2 + (y[l] * y[m]) * G[l * NL + m];
+  live = tw_value(n2) >= 1e-24f;
+  inv = live ? tw_rsqrt(n2) : S(1e12f);
+}
+
+// reverse sweep: gw (already masked) -> gc, gG
+template <class S, int NL>
+__device__ __forceinline__ void tw_grad(S c, const S* G, const float* gw, S& gc, S* gG) {
+  S y[NL], inv;
+  bool live;
+  tw_eval<S, NL>(c, G, y, inv, live);
+  S gy[NL], g_inv = S(0.f);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    gy[l] = gw[l] * inv;
+    g_inv = g_inv + gw[l] * y[l];
+  }
+  const S g_n2 = live ? (-0.5f) * (g_inv * (inv * (inv * inv))) : S(0.f);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    S acc = S(0.f);
+#pragma unroll
+    for (int m = 0; m < NL; ++m) {
+      gG[l * NL + m] = g_n2 * (y[l] * y[m]);
+      acc = acc + (G[l * NL + m] + G[m * NL + l]) * y[m];
+    }
+    gy[l] = gy[l] + g_n2 * acc;
+  }
+  gc = S(0.f);
+  if (NL > 1) gc = gc + TW_Y1 * gy[1];
+  if (NL > 2) gc = gc + (2.0f * TW_Y2A) * (c * gy[2]);
+  if (NL > 3) gc = gc + TW_Y3 * ((15.0f * (c * c) - 3.0f) * gy[3]);
+}
+
+template <int NL>
+__device__ __forceinline__ void tw_store(float* __restrict__ p, const float* v) {
+  if (NL == 4) *(f32x4v*)p = f32x4v{v[0], v[1], v[2], v[3]};    // (T, 4) rows are 16-byte aligned
+  else
+#pragma unroll
+    for (int l = 0; l < NL; ++l) p[l] = v[l];
+}
+template <int NL>
+__device__ __forceinline__ void tw_load(const float* __restrict__ p, float* v) {
+  if (NL == 4) {
+    const f32x4v x = *(const f32x4v*)p;
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3 % NL] = x[3];
+  } else
+#pragma unroll
+    for (int l = 0; l < NL; ++l) v[l] = p[l];
+}
+
+// MODE 0: w;  1: gc, gG from gw;  2: ggw, gc2, gG2 from (hc, hG, gw)
+template <int NL, int MODE>
+__global__ void k_trip_weight(const float* __restrict__ c, const float* __restrict__ G, const float* __restrict__ gw,
+                              const float* __restrict__ hc, const float* __restrict__ hG,
+                              const int32_t* __restrict__ dst_p, const int32_t* __restrict__ in_ptr,
+                              const int32_t* __restrict__ in_pos, const int32_t* __restrict__ out_ptr,
+                              const int64_t* __restrict__ tbase, int64_t n_edges, int n_centres,
+                              float* __restrict__ o_w, float* __restrict__ o_c, float* __restrict__ o_G) {
+  constexpr int NG = NL * NL;
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k >= n_edges) return;
+  const int q = in_pos[k];
+  const int s = dst_p[q];
+  if (s >= n_centres) {   // in-edge of a node that is no centre here: no triplets; its G row gets a zero gradient
+    if (MODE != 0)
+#pragma unroll
+      for (int a = 0; a < NG; ++a) o_G[(int64_t)q * NG + a] = 0.f;
+    return;
+  }
+  const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
+  const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
+  float g[NG], dg[NG], accG[NG];
+#pragma unroll
+  for (int a = 0; a < NG; ++a) {
+    g[a] = G[(int64_t)q * NG + a];
+    dg[a] = MODE == 2 ? hG[(int64_t)q * NG + a] : 0.f;
+    accG[a] = 0.f;
+  }
+  int64_t t = tbase[s] + (k - j0);
+  for (int i = 0; i < m_out; ++i, t += m_in) {
+    const float cc = c[t];
+    const bool keep = (p0 + i) != q;
+    if (MODE == 0) {
+      float y[NL], inv;
+      bool live;
+      tw_eval<float, NL>(cc, g, y, inv, live);
+      float wv[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) wv[l] = keep ? y[l] * inv : 0.f;
+      tw_store<NL>(o_w + t * NL, wv);
+    } else {
+      float gwt[NL];
+      tw_load<NL>(gw + t * NL, gwt);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) gwt[l] = keep ? gwt[l] : 0.f;
+      if (MODE == 1) {
+        float gc, gG[NG];
+        tw_grad<float, NL>(cc, g, gwt, gc, gG);
+        o_c[t] = gc;
+#pragma unroll
+        for (int a = 0; a < NG; ++a) accG[a] += gG[a];
+      } else {
+        TwDual Gd[NG], gc, gG[NG], y[NL], inv;
+#pragma unroll
+        for (int a = 0; a < NG; ++a) Gd[a] = TwDual(g[a], dg[a]);
+        const TwDual cd(cc, hc[t]);
+        tw_grad<TwDual, NL>(cd, Gd, gwt, gc, gG);
+        o_c[t] = gc.d;
+#pragma unroll
+        for (int a = 0; a < NG; ++a) accG[a] += gG[a].d;
+        bool live;
+        tw_eval<TwDual, NL>(cd, Gd, y, inv, live);
+        float wv[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) wv[l] = keep ? (y[l] * inv).d : 0.f;             // J h: the gradient wrt gw
+        tw_store<NL>(o_w + t * NL, wv);
+      }
+    }
+  }
+  if (MODE != 0)
+#pragma unroll
+    for (int a = 0; a < NG; ++a) o_G[(int64_t)q * NG + a] = accG[a];
+}
+
 static int check_trip(int64_t n_edges, int V, int n_l) {
   if (n_edges < 0 || n_edges >= (int64_t(1) << 31)) return LCAO_ERR_INVALID;
   if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
@@ -523,5 +693,64 @@ extern "C" int lcao_rowmix(const float* S, const float* A, int64_t n_edges, int 
   else if (R_ <= 4) MM(4);
   else MM(8);
 #undef MM
+  return lcao_launch_status();
+}
+
+#define TW_DISPATCH(MODE, ...)                                                                                  \
+  do {                                                                                                          \
+    dim3 grid(lcao_blocks(n_edges, 256)), block(256);                                                           \
+    if (n_l == 1) hipLaunchKernelGGL((k_trip_weight<1, MODE>), grid, block, 0, st, __VA_ARGS__);                \
+    else if (n_l == 2) hipLaunchKernelGGL((k_trip_weight<2, MODE>), grid, block, 0, st, __VA_ARGS__);           \
+    else if (n_l == 3) hipLaunchKernelGGL((k_trip_weight<3, MODE>), grid, block, 0, st, __VA_ARGS__);           \
+    else hipLaunchKernelGGL((k_trip_weight<4, MODE>), grid, block, 0, st, __VA_ARGS__);                         \
+  } while (0)
+
+static int check_tw(int64_t n_edges, int64_t n_centres, int n_l) {
+  if (n_edges < 0 || n_edges >= (int64_t(1) << 31)) return LCAO_ERR_INVALID;
+  if (n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
+  return check_centres(n_centres);
+}
+
+extern "C" int lcao_trip_weight(const float* c, const float* G, const int32_t* dst_p, const int32_t* in_ptr,
+                                const int32_t* in_pos, const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges,
+                                int64_t n_centres, int n_l, float* w, void* stream) {
+  int rc = check_tw(n_edges, n_centres, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(c); LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(in_ptr); LCAO_CHECK_PTR(in_pos);
+  LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(w);
+  hipStream_t st = (hipStream_t)stream;
+  TW_DISPATCH(0, c, G, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dst_p, in_ptr, in_pos, out_ptr,
+              tbase, n_edges, (int)n_centres, w, (float*)nullptr, (float*)nullptr);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_trip_weight_bwd(const float* gw, const float* c, const float* G, const int32_t* dst_p,
+                                    const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr,
+                                    const int64_t* tbase, int64_t n_edges, int64_t n_centres, int n_l, float* gc,
+                                    float* gG, void* stream) {
+  int rc = check_tw(n_edges, n_centres, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(gw); LCAO_CHECK_PTR(c); LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(in_ptr);
+  LCAO_CHECK_PTR(in_pos); LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(gc); LCAO_CHECK_PTR(gG);
+  hipStream_t st = (hipStream_t)stream;
+  TW_DISPATCH(1, c, G, gw, (const float*)nullptr, (const float*)nullptr, dst_p, in_ptr, in_pos, out_ptr, tbase, n_edges,
+              (int)n_centres, (float*)nullptr, gc, gG);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_trip_weight_bwd2(const float* hc, const float* hG, const float* gw, const float* c, const float* G,
+                                     const int32_t* dst_p, const int32_t* in_ptr, const int32_t* in_pos,
+                                     const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres,
+                                     int n_l, float* ggw, float* gc2, float* gG2, void* stream) {
+  int rc = check_tw(n_edges, n_centres, n_l);
+  if (rc != LCAO_OK) return rc;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(hc); LCAO_CHECK_PTR(hG); LCAO_CHECK_PTR(gw); LCAO_CHECK_PTR(c); LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(dst_p);
+  LCAO_CHECK_PTR(in_ptr); LCAO_CHECK_PTR(in_pos); LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(ggw);
+  LCAO_CHECK_PTR(gc2); LCAO_CHECK_PTR(gG2);
+  hipStream_t st = (hipStream_t)stream;
+  TW_DISPATCH(2, c, G, gw, hc, hG, dst_p, in_ptr, in_pos, out_ptr, tbase, n_edges, (int)n_centres, ggw, gc2, gG2);
   return lcao_launch_status();
 }

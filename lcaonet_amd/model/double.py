@@ -24,14 +24,11 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import ops
 from ..data.keys import GraphKeys
 
-Y0 = 0.28209479177387814
-Y1 = 0.48860251190292
-Y2A, Y2B = 0.94617469575756, 0.31539156525252
-Y3 = 0.373176332590115
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -183,17 +180,29 @@ class _Geo:
         self.tbase = (torch.cumsum(prod, 0) - prod).contiguous()
         T = int(prod.sum().item())                                   # host sync: this mode sizes T-long scalar tensors
         self.T = T
-        node = torch.repeat_interleave(torch.arange(self.N, device=dev), prod, output_size=T)
-        local = torch.arange(T, device=dev) - self.tbase[node]
-        mi = m_in[node].clamp(min=1)
-        tri_p = ctx.out_ptr[:-1].long()[node] + torch.div(local, mi, rounding_mode="floor")
-        tri_q = ctx.in_pos.long()[ctx.in_ptr[:-1].long()[node] + local % mi]
-        self.tp, self.tq = IndexPlan(tri_p, self.E, is_sorted=True), IndexPlan(tri_q, self.E)
-        self.tmask = (tri_p != tri_q).float().unsqueeze(1)           # lcaonet.py:470 drops the pair q == p
+        self._prod, self._m_in, self._tri = prod, m_in, None
         in_rank = torch.empty(self.E, dtype=torch.int32, device=dev)
         k = torch.arange(self.E, device=dev)
         in_rank[ctx.in_pos.long()] = (k - ctx.in_ptr[:-1].long()[ctx.dst_p.long()[ctx.in_pos.long()]]).to(torch.int32)
         self.in_rank = in_rank
+
+    def _triplet_lists(self):
+        """Explicit (out-edge, in-edge) index lists of the triplet slots — T-long; the kernels never need them (they walk
+        the per-node blocks), only tests and diagnostics do."""
+        if self._tri is None:
+            ctx, dev, T = self.ctx, self.z.device, self.T
+            node = torch.repeat_interleave(torch.arange(self.N, device=dev), self._prod, output_size=T)
+            local = torch.arange(T, device=dev) - self.tbase[node]
+            mi = self._m_in[node].clamp(min=1)
+            tri_p = ctx.out_ptr[:-1].long()[node] + torch.div(local, mi, rounding_mode="floor")
+            tri_q = ctx.in_pos.long()[ctx.in_ptr[:-1].long()[node] + local % mi]
+            self._tri = (IndexPlan(tri_p, self.E, is_sorted=True), IndexPlan(tri_q, self.E),
+                         (tri_p != tri_q).float().unsqueeze(1))      # lcaonet.py:470 drops the pair q == p
+        return self._tri
+
+    tp = property(lambda self: self._triplet_lists()[0])
+    tq = property(lambda self: self._triplet_lists()[1])
+    tmask = property(lambda self: self._triplet_lists()[2])
 
     def _pair_lists(self, pair_p: Tensor, chunk: int = 64):
         zz = self.zdim * self.zdim
@@ -385,16 +394,47 @@ def _mlp(seq, x: Tensor) -> Tensor:
     return x
 
 
+class _TripletWeightFn(Function):
+    """w = w(c, G) (csrc/lcao_double.hip::k_trip_weight); backward is itself a Function, so it can be differentiated."""
+
+    @staticmethod
+    def forward(ctx, c, G, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(c, G)
+        return ops.trip_weight(c, G, geo)
+
+    @staticmethod
+    def backward(ctx, gw):
+        c, G = ctx.saved_tensors
+        gc, gG = _TripletWeightBwdFn.apply(gw.contiguous(), c, G, ctx.geo)
+        return gc, gG, None
+
+
+class _TripletWeightBwdFn(Function):
+    @staticmethod
+    def forward(ctx, gw, c, G, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(gw, c, G)
+        return ops.trip_weight_bwd(gw, c, G, geo)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hc, hG):
+        gw, c, G = ctx.saved_tensors
+        hc = torch.zeros_like(c) if hc is None else hc.contiguous()
+        hG = torch.zeros_like(G) if hG is None else hG.contiguous()
+        ggw, gc2, gG2 = ops.trip_weight_bwd2(hc, hG, gw, c, G, ctx.geo)
+        return ggw, gc2, gG2, None
+
+
 def _triplet_weights(geo: _Geo, u: Tensor, G: Tensor) -> Tensor:
-    """w[t, l] = Y_l(u_p . u_q) / max(sqrt(Y^T G_q Y), 1e-12), zero for q == p  (lcaonet.py:179-184 in Gram form)."""
-    n_l = geo.n_l
-    c = (gather(u, geo.tp) * gather(u, geo.tq)).sum(dim=1)
-    ys = [torch.full_like(c, Y0), Y1 * c, Y2A * c * c - Y2B, Y3 * c * (5.0 * c * c - 3.0)][:n_l]
-    y = torch.stack(ys, dim=1)                                               # (T, n_l)
-    Gq = gather(G.reshape(geo.E, n_l * n_l), geo.tq).reshape(-1, n_l, n_l)
-    n2 = ((Gq * y.unsqueeze(1)).sum(dim=2) * y).sum(dim=1)                    # y^T G_q y (no batched-GEMM call)
-    inv = torch.rsqrt(torch.clamp_min(n2, 1e-24))
-    return y * inv.unsqueeze(1) * geo.tmask
+    """w[t, l] = Y_l(u_p . u_q) / max(sqrt(Y^T G_q Y), 1e-12), zero for q == p  (lcaonet.py:179-184 in Gram form).
+    The cosines are an sddmm of the (zero-padded) unit vectors with themselves — the bilinear family again — and the
+    nonlinear map (c, G) -> w is one kernel with hand-written first and second derivatives: no T-long tensor passes
+    through an elementwise torch op."""
+    u4 = F.pad(u, (0, 1))
+    c = _SddmmFn.apply(u4, u4.unsqueeze(1), geo).squeeze(1)                    # (T,)
+    return _TripletWeightFn.apply(c, G, geo)
 
 
 def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_direct_forces: bool = False, shard=None):

@@ -707,6 +707,49 @@ def trip_sddmm(G, A, geo):
     return out
 
 
+def _tw_args(geo):
+    c = geo.ctx
+    return (_p(c.dst_p), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr), _p(geo.tbase), geo.E, geo.n_own)
+
+
+def _tw_check(c, G, geo):
+    n_l = G.shape[1]
+    if tuple(c.shape) != (geo.T,) or tuple(G.shape) != (geo.E, n_l, n_l):
+        raise ValueError(f"trip_weight: c {tuple(c.shape)} must be ({geo.T},) and G {tuple(G.shape)} (E={geo.E}, n_l, n_l)")
+    return n_l
+
+
+def trip_weight(c, G, geo):
+    """w[t,l] = [p != q] Y_l(c_t) / sqrt(max(Y^T G_q Y, 1e-24));  c (T,), G (E, n_l, n_l) -> (T, n_l)."""
+    c, G = _f32(c, "c"), _f32(G, "G")
+    n_l = _tw_check(c, G, geo)
+    w = torch.zeros(geo.T, n_l, device=c.device, dtype=torch.float32)
+    _call("lcao_trip_weight", _p(c), _p(G), *_tw_args(geo), n_l, _p(w), _stream())
+    return w
+
+
+def trip_weight_bwd(gw, c, G, geo):
+    """(gc (T,), gG (E, n_l, n_l)): the reverse sweep of trip_weight."""
+    gw, c, G = _f32(gw, "gw"), _f32(c, "c"), _f32(G, "G")
+    n_l = _tw_check(c, G, geo)
+    gc = torch.zeros(geo.T, device=c.device, dtype=torch.float32)
+    gG = torch.empty_like(G)
+    _call("lcao_trip_weight_bwd", _p(gw), _p(c), _p(G), *_tw_args(geo), n_l, _p(gc), _p(gG), _stream())
+    return gc, gG
+
+
+def trip_weight_bwd2(hc, hG, gw, c, G, geo):
+    """Reverse sweep of trip_weight_bwd for cotangents (hc, hG) of (gc, gG): (ggw (T, n_l), gc2 (T,), gG2 (E, n_l, n_l))."""
+    hc, hG, gw, c, G = _f32(hc, "hc"), _f32(hG, "hG"), _f32(gw, "gw"), _f32(c, "c"), _f32(G, "G")
+    n_l = _tw_check(c, G, geo)
+    ggw = torch.zeros(geo.T, n_l, device=c.device, dtype=torch.float32)
+    gc2 = torch.zeros(geo.T, device=c.device, dtype=torch.float32)
+    gG2 = torch.empty_like(G)
+    _call("lcao_trip_weight_bwd2", _p(hc), _p(hG), _p(gw), _p(c), _p(G), *_tw_args(geo), n_l, _p(ggw), _p(gc2), _p(gG2),
+          _stream())
+    return ggw, gc2, gG2
+
+
 def rowgram(X, Y):
     """out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]  — per-edge Gram matrices (E, n_l, n_l)."""
     X, Y = _f32(X, "X"), _f32(Y, "Y")

@@ -149,6 +149,54 @@ def test_trip_bilinear_family_is_consistent(dev):
         assert relerr(ops.trip_sddmm(G, A, geo), want_d) <= 2e-6
 
 
+def test_triplet_weight_kernels_first_and_second_derivatives(dev):
+    """csrc/lcao_double.hip k_trip_weight (w = Y_l(c) / |.|_G with the q == p slot dropped, lcaonet.py:175-184,470): values,
+    gradient and gradient-of-gradient against the same function from fp64 tensor ops under autograd."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import LCAONet
+    from lcaonet_amd.model.double import _Geo, _TripletWeightFn
+    g = random_periodic_cells(2, 12, 6.0, 0.99 * 4.5, seed=5).to(dev)
+    m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=32, n_interaction=1, cutoff=4.5).to(dev)
+    ys = (lambda c: torch.full_like(c, 0.28209479177387814), lambda c: 0.48860251190292 * c,
+          lambda c: 0.94617469575756 * c * c - 0.31539156525252, lambda c: 0.373176332590115 * c * (5.0 * c * c - 3.0))
+    for n_l in (1, 2, 3, 4):
+        geo = _Geo(m, g)
+        geo.n_l = n_l
+        E, T = geo.E, geo.T
+        tq, tmask = geo.tq.idx, geo.tmask.double()
+        gen = torch.Generator(device="cpu").manual_seed(n_l)
+        c0 = (2.0 * torch.rand(T, generator=gen) - 1.0).to(dev)
+        B = torch.randn(E, n_l, 6, generator=gen).to(dev)
+        G0 = torch.einsum("elv,emv->elm", B, B) + 0.05 * torch.randn(E, n_l, n_l, generator=gen).to(dev)  # not symmetric
+        G0[0] = 0.0                                          # a clamped row: |.| = 1e-12, no gradient through the norm
+        R, Hc, HG = (torch.randn(T, n_l, generator=gen).to(dev), torch.randn(T, generator=gen).to(dev),
+                     torch.randn(E, n_l, n_l, generator=gen).to(dev))
+
+        def ref(c, G):
+            y = torch.stack([f(c) for f in ys[:n_l]], dim=1)
+            n2 = torch.einsum("tl,tlm,tm->t", y, G[tq], y)
+            return y * torch.rsqrt(torch.clamp_min(n2, 1e-24)).unsqueeze(1) * tmask.to(c.dtype)
+
+        def chain(fn, c, G, R_, Hc_, HG_):
+            c, G, R_ = c.clone().requires_grad_(True), G.clone().requires_grad_(True), R_.clone().requires_grad_(True)
+            w = fn(c, G)
+            gc, gG = torch.autograd.grad((w * R_).sum(), (c, G), create_graph=True, allow_unused=True)
+            gc = torch.zeros_like(c) if gc is None else gc            # n_l = 1: no dependence on the angle
+            second = torch.autograd.grad((gc * Hc_).sum() + (gG * HG_).sum(), (c, G, R_), allow_unused=True)
+            second = [torch.zeros_like(x) if s_ is None else s_ for s_, x in zip(second, (c, G, R_))]
+            return (w.detach(), gc.detach(), gG.detach()) + tuple(second)
+        got = chain(lambda c, G: _TripletWeightFn.apply(c, G, geo), c0, G0, R, Hc, HG)
+        want = chain(ref, c0.double(), G0.double(), R.double(), Hc.double(), HG.double())
+        live = torch.ones(E, dtype=torch.bool, device=dev)
+        live[0] = False                                      # the clamped row's w is ~1e12 y: compare the others in relerr
+        tl = live[tq]
+        names = ("w", "gc", "gG", "d2/dc", "d2/dG", "d2/dgw")
+        for name, a, b in zip(names, got, want):
+            mask = tl if a.shape[0] == T else live
+            assert relerr(a[mask], b[mask]) <= 2e-5, (n_l, name)
+            assert torch.allclose(a[~mask].double(), b[~mask], rtol=1e-4, atol=0.0) or name != "w", (n_l, name)
+
+
 def test_rowgram_family_first_and_second_derivatives(dev):
     """csrc/lcao_double.hip rowgram / rowmix (the per-edge Gram matrix of lcaonet.py:179-184 and its derivatives): values
     against fp64 einsums, and gradient + gradient-of-gradient through model/double.py's Functions against autograd of
