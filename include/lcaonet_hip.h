@@ -366,6 +366,14 @@ int lcao_trip_weight_bwd2(const float* hc, const float* hG, const float* gw, con
                           const int64_t* tbase, int64_t n_edges, int64_t n_centres, int n_l, float* ggw, float* gc2,
                           float* gG2, void* stream);
 
+/* SiLU and row normalisation (F.normalize, lcaonet.py:196) with closed-form first and second derivatives; `level` selects
+ * 0: y(x) -> out0;  1: reverse sweep for cotangent g -> out0;  2: reverse sweep of level 1 for its cotangent h:
+ * out0 = d/dg, out1 = d/dx.  Unused inputs / outputs of a level may be NULL. */
+int lcao_silu_levels(int level, const float* x, const float* g, const float* h, int64_t n, float* out0, float* out1,
+                     void* stream);
+int lcao_rownorm_levels(int level, const float* x, const float* g, const float* k, int64_t n_rows, int V, float eps,
+                        float* out0, float* out1, void* stream);
+
 /* The per-edge Gram matrix of lcaonet.py:179-184 (|sum_l Y_l A[q,l,:]|^2 = Y^T G_q Y, G_q = A_q A_q^T) as a second closed
  * family:  rowgram: out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]   (E, n_l, n_l)
  *          rowmix : out[e,l,v] = sum_m S[e,l,m] A[e,m,v]   (E, n_l, V); trans != 0 reads S[e,m,l]

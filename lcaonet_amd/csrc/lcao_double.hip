@@ -568,6 +568,100 @@ __global__ void k_trip_weight(const float* __restrict__ c, const float* __restri
     for (int a = 0; a < NG; ++a) o_G[(int64_t)q * NG + a] = accG[a];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pointwise / row-wise pieces of the edge chain with their first and second derivatives in closed form, so that the
+// (E, V) tensors of the double backward pass through one kernel per level instead of autograd's decomposition:
+//   SiLU (lcaonet.py:142-150 f_node activations):  s1 = sig (1 + x (1 - sig)),  s2 = sig (1 - sig) (2 + x (1 - 2 sig))
+//     level 0: y = x sig        level 1: gx = g s1        level 2 (cotangent h of gx): gg = h s1,  gx2 = h g s2
+//   row normalisation y = x / max(|x|, eps) (lcaonet.py:196, F.normalize), n = |x|, a = y.k, b = y.g, d = k.g:
+//     level 1: gx = (g - y b) / n        level 2 (cotangent k of gx): gg = (k - y a) / n,
+//                                        gx2 = ((3 a b - d) y - b k - a g) / n^2;   rows with n <= eps: x / eps, g / eps, 0
+// ---------------------------------------------------------------------------------------------------------------------
+template <int LEVEL>
+__global__ void k_silu_levels(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ h,
+                              int64_t n, float* __restrict__ o0, float* __restrict__ o1) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    float xv[4], gv[4], hv[4], a0[4], a1[4];
+    const bool full = i + 4 <= n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = full || i + j < n;
+      xv[j] = ok ? x[i + j] : 0.f;
+      gv[j] = (LEVEL >= 1 && ok) ? g[i + j] : 0.f;
+      hv[j] = (LEVEL >= 2 && ok) ? h[i + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sg = 1.0f / (1.0f + __expf(-xv[j]));
+      const float s1 = sg * (1.0f + xv[j] * (1.0f - sg));
+      if (LEVEL == 0) a0[j] = xv[j] * sg;
+      if (LEVEL == 1) a0[j] = gv[j] * s1;
+      if (LEVEL == 2) {
+        a0[j] = hv[j] * s1;
+        a1[j] = hv[j] * gv[j] * (sg * (1.0f - sg) * (2.0f + xv[j] * (1.0f - 2.0f * sg)));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (full || i + j < n) {
+        o0[i + j] = a0[j];
+        if (LEVEL == 2) o1[i + j] = a1[j];
+      }
+  }
+}
+
+template <int R, int LEVEL>
+__global__ void k_rownorm_levels(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ k,
+                                 int64_t n_rows, int V, float eps, float* __restrict__ o0, float* __restrict__ o1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; e < n_rows; e += nwave) {
+    float xv[R], gv[R], kv[R];
+    float n2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ch = lane + 64 * r;
+      const bool ok = ch < V;
+      xv[r] = ok ? x[e * V + ch] : 0.f;
+      gv[r] = (LEVEL >= 1 && ok) ? g[e * V + ch] : 0.f;
+      kv[r] = (LEVEL >= 2 && ok) ? k[e * V + ch] : 0.f;
+      n2 += xv[r] * xv[r];
+    }
+    const float n = sqrtf(lcao_wave_sum(n2));
+    const bool live = n > eps;
+    const float inv = 1.0f / fmaxf(n, eps);
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (LEVEL >= 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        b += xv[r] * gv[r];
+        if (LEVEL >= 2) {
+          a += xv[r] * kv[r];
+          d += kv[r] * gv[r];
+        }
+      }
+      b = lcao_wave_sum(b) * inv;
+      if (LEVEL >= 2) {
+        a = lcao_wave_sum(a) * inv;
+        d = lcao_wave_sum(d);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ch = lane + 64 * r;
+      if (ch >= V) continue;
+      const float y = xv[r] * inv;
+      if (LEVEL == 0) o0[e * V + ch] = y;
+      if (LEVEL == 1) o0[e * V + ch] = live ? (gv[r] - y * b) * inv : gv[r] * inv;
+      if (LEVEL == 2) {
+        o0[e * V + ch] = live ? (kv[r] - y * a) * inv : kv[r] * inv;
+        o1[e * V + ch] = live ? ((3.0f * a * b - d) * y - b * kv[r] - a * gv[r]) * (inv * inv) : 0.f;
+      }
+    }
+  }
+}
+
 static int check_trip(int64_t n_edges, int V, int n_l) {
   if (n_edges < 0 || n_edges >= (int64_t(1) << 31)) return LCAO_ERR_INVALID;
   if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
@@ -752,5 +846,47 @@ extern "C" int lcao_trip_weight_bwd2(const float* hc, const float* hG, const flo
   LCAO_CHECK_PTR(gc2); LCAO_CHECK_PTR(gG2);
   hipStream_t st = (hipStream_t)stream;
   TW_DISPATCH(2, c, G, gw, hc, hG, dst_p, in_ptr, in_pos, out_ptr, tbase, n_edges, (int)n_centres, ggw, gc2, gG2);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_silu_levels(int level, const float* x, const float* g, const float* h, int64_t n, float* out0,
+                                float* out1, void* stream) {
+  if (n < 0 || level < 0 || level > 2) return LCAO_ERR_INVALID;
+  if (n == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(x); LCAO_CHECK_PTR(out0);
+  if (level >= 1) LCAO_CHECK_PTR(g);
+  if (level >= 2) { LCAO_CHECK_PTR(h); LCAO_CHECK_PTR(out1); }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks((n + 3) / 4, 256, 65536)), block(256);
+  if (level == 0) hipLaunchKernelGGL(k_silu_levels<0>, grid, block, 0, st, x, g, h, n, out0, out1);
+  else if (level == 1) hipLaunchKernelGGL(k_silu_levels<1>, grid, block, 0, st, x, g, h, n, out0, out1);
+  else hipLaunchKernelGGL(k_silu_levels<2>, grid, block, 0, st, x, g, h, n, out0, out1);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_rownorm_levels(int level, const float* x, const float* g, const float* k, int64_t n_rows, int V,
+                                   float eps, float* out0, float* out1, void* stream) {
+  if (n_rows < 0 || V <= 0 || level < 0 || level > 2) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  if (n_rows == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(x); LCAO_CHECK_PTR(out0);
+  if (level >= 1) LCAO_CHECK_PTR(g);
+  if (level >= 2) { LCAO_CHECK_PTR(k); LCAO_CHECK_PTR(out1); }
+  hipStream_t st = (hipStream_t)stream;
+  const int R_ = (V + 63) / 64;
+  dim3 grid(lcao_blocks(n_rows, 4, 65536)), block(256);
+#define RN(RR, LL) hipLaunchKernelGGL((k_rownorm_levels<RR, LL>), grid, block, 0, st, x, g, k, n_rows, V, eps, out0, out1)
+#define RNL(RR)            \
+  do {                     \
+    if (level == 0) RN(RR, 0); \
+    else if (level == 1) RN(RR, 1); \
+    else RN(RR, 2);        \
+  } while (0)
+  if (R_ == 1) RNL(1);
+  else if (R_ == 2) RNL(2);
+  else if (R_ <= 4) RNL(4);
+  else RNL(8);
+#undef RNL
+#undef RN
   return lcao_launch_status();
 }

@@ -167,7 +167,7 @@ class _Geo:
         shift = graph[GraphKeys.Edge_shift][order].float()
         lat = graph[GraphKeys.Lattice].float().reshape(-1, 3, 3)
         b_src = batch[ctx.src_p.long()] if batch is not None else torch.zeros(self.E, dtype=torch.long, device=dev)
-        self.cell_shift = torch.einsum("ni,nij->nj", shift, lat[b_src]).contiguous()      # constant part of edge vectors
+        self.cell_shift = (shift.unsqueeze(2) * lat[b_src]).sum(dim=1).contiguous()       # shift @ lattice: constant part
         # pair rows and the pair-sorted chunk lists of lcao_pair_table_grad
         self.ones_gate = torch.ones(self.N, model.emb_size_conv, device=dev)
         pair_p = z[ctx.src_p.long()] * self.zdim + z[ctx.dst_p.long()]
@@ -378,6 +378,20 @@ class _RowMixFn(Function):
         return gS, (_RowMixFn.apply(S, g, not ctx.trans) if ctx.needs_input_grad[1] else None), None
 
 
+class _GramFn(Function):
+    """G = A A^T per edge: rowgram(A, A) with ONE gradient, rowmix(g + g^T, A), instead of two that autograd would add."""
+
+    @staticmethod
+    def forward(ctx, A):
+        ctx.save_for_backward(A)
+        return ops.rowgram(A, A)
+
+    @staticmethod
+    def backward(ctx, g):
+        (A,) = ctx.saved_tensors
+        return _RowMixFn.apply((g + g.transpose(1, 2)).contiguous(), A, False)
+
+
 def rowgram(X: Tensor, Y: Tensor) -> Tensor:
     """out[e,l,m] = X[e,l,:] . Y[e,m,:]  (twice differentiable)."""
     return _RowGramFn.apply(X.contiguous(), Y.contiguous())
@@ -392,6 +406,45 @@ def _mlp(seq, x: Tensor) -> Tensor:
     for m in seq:
         x = dense(x, m.weight, m.bias) if isinstance(m, Dense) else m(x)
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pointwise / row-wise functions with closed-form first and second derivatives (one kernel per level)
+# ---------------------------------------------------------------------------------------------------------------------
+def _levels_functions(op):
+    """(Fn, BwdFn) for a map y = f(x) whose `op(level, x, g, h)` gives f, the reverse sweep and the reverse sweep of that."""
+    class Fn(Function):
+        @staticmethod
+        def forward(ctx, x):
+            ctx.save_for_backward(x)
+            return op(0, x)
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            return Bwd.apply(g.contiguous(), x)
+
+    class Bwd(Function):
+        @staticmethod
+        def forward(ctx, g, x):
+            ctx.save_for_backward(g, x)
+            return op(1, x, g)
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, h):
+            g, x = ctx.saved_tensors
+            return op(2, x, g, h.contiguous())
+
+    return Fn, Bwd
+
+
+_SiluFn, _SiluBwdFn = _levels_functions(ops.silu_levels)
+_RowNormFn, _RowNormBwdFn = _levels_functions(ops.rownorm_levels)
+
+
+def _activation(module, x: Tensor) -> Tensor:
+    return _SiluFn.apply(x.contiguous()) if type(module) is torch.nn.SiLU else module(x)
 
 
 class _TripletWeightFn(Function):
@@ -474,7 +527,7 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
             A = _ContractFn.apply(rb, Tf, geo)
             B, Bv = A.sum(dim=1), None
         Ag = A * gather(gate, geo.src).unsqueeze(1)
-        G = rowgram(A, A)
+        G = _GramFn.apply(A.contiguous())
         tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)               # (e_own, V)
         ft = dense(tbw, layer.f_three[0].weight)
         B = B[: geo.e_own]
@@ -483,9 +536,9 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
         else:
             Bv = Bv[: geo.e_own]
             lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
-        bw = dense(F.normalize(lw_in, dim=-1), layer.basis_weight.weight)
-        h1 = layer.f_node[1](gather(Ps, geo.src_o) + gather(Pt, geo.dst_o))
-        h2 = layer.f_node[3](dense(h1, layer.f_node[2].weight, layer.f_node[2].bias))
+        bw = dense(_RowNormFn.apply(lw_in.contiguous()), layer.basis_weight.weight)       # F.normalize(dim=-1)
+        h1 = _activation(layer.f_node[1], gather(Ps, geo.src_o) + gather(Pt, geo.dst_o))
+        h2 = _activation(layer.f_node[3], dense(h1, layer.f_node[2].weight, layer.f_node[2].bias))
         x = x[:n_own] + dense(scatter_sum(bw * h2, geo.agg), layer.out_weight.weight)
     prop = _mlp(model.out_layer.out_lin, x)
     batch = graph.get(GraphKeys.Batch_idx)

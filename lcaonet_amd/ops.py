@@ -750,6 +750,37 @@ def trip_weight_bwd2(hc, hG, gw, c, G, geo):
     return ggw, gc2, gG2
 
 
+def silu_levels(level: int, x, g=None, h=None):
+    """SiLU with closed-form derivatives (csrc/lcao_double.hip): level 0 -> y; 1 -> g s1(x); 2 -> (h s1(x), h g s2(x))."""
+    x = _f32(x, "x")
+    g = None if g is None else _f32(g, "g")
+    h = None if h is None else _f32(h, "h")
+    for t in (g, h):
+        if t is not None and t.shape != x.shape:
+            raise ValueError("silu_levels: operands must have one shape")
+    o0 = torch.empty_like(x)
+    o1 = torch.empty_like(x) if level == 2 else None
+    _call("lcao_silu_levels", level, _p(x), _p(g) if g is not None else None, _p(h) if h is not None else None,
+          x.numel(), _p(o0), _p(o1) if o1 is not None else None, _stream())
+    return o0 if level < 2 else (o0, o1)
+
+
+def rownorm_levels(level: int, x, g=None, k=None, eps: float = 1e-12):
+    """x / max(|x|, eps) along the last dim with closed-form derivatives; levels as silu_levels."""
+    x = _f32(x, "x")
+    g = None if g is None else _f32(g, "g")
+    k = None if k is None else _f32(k, "k")
+    for t in (g, k):
+        if t is not None and t.shape != x.shape:
+            raise ValueError("rownorm_levels: operands must have one shape")
+    V = x.shape[-1]
+    o0 = torch.empty_like(x)
+    o1 = torch.empty_like(x) if level == 2 else None
+    _call("lcao_rownorm_levels", level, _p(x), _p(g) if g is not None else None, _p(k) if k is not None else None,
+          x.numel() // max(V, 1), V, float(eps), _p(o0), _p(o1) if o1 is not None else None, _stream())
+    return o0 if level < 2 else (o0, o1)
+
+
 def rowgram(X, Y):
     """out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]  — per-edge Gram matrices (E, n_l, n_l)."""
     X, Y = _f32(X, "X"), _f32(Y, "Y")

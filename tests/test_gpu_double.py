@@ -197,6 +197,38 @@ def test_triplet_weight_kernels_first_and_second_derivatives(dev):
             assert torch.allclose(a[~mask].double(), b[~mask], rtol=1e-4, atol=0.0) or name != "w", (n_l, name)
 
 
+@pytest.mark.parametrize("which", ["silu", "rownorm"])
+def test_pointwise_levels_first_and_second_derivatives(dev, which):
+    """csrc/lcao_double.hip k_silu_levels / k_rownorm_levels (the f_node activations and F.normalize of lcaonet.py:142-150,
+    196): value, gradient and gradient-of-gradient against torch autograd of the fp64 function."""
+    from lcaonet_amd.model.double import _RowNormFn, _SiluFn
+    fn, ref = {"silu": (_SiluFn.apply, torch.nn.functional.silu),
+               "rownorm": (_RowNormFn.apply, lambda t: torch.nn.functional.normalize(t, dim=-1))}[which]
+    for shape in ((1, 1), (37, 48), (501, 128), (5, 200), (3, 512), (1030, 7)):
+        if which == "rownorm" and shape[1] == 1:
+            continue                                         # y = sign(x): every derivative is exactly zero
+        gen = torch.Generator(device="cpu").manual_seed(shape[0] + shape[1])
+        x0 = (3.0 * torch.randn(*shape, generator=gen)).to(dev)
+        if which == "rownorm" and shape[0] > 2:
+            x0[1] = 0.0                                      # a clamped row: y = x / eps, g / eps, no curvature
+        R, H = torch.randn(*shape, generator=gen).to(dev), torch.randn(*shape, generator=gen).to(dev)
+
+        def chain(f, x, R_, H_):
+            x, R_ = x.clone().requires_grad_(True), R_.clone().requires_grad_(True)
+            y = f(x)
+            (gx,) = torch.autograd.grad((y * R_).sum(), x, create_graph=True)
+            g2x, g2r = torch.autograd.grad((gx * H_).sum(), (x, R_))
+            return y.detach(), gx.detach(), g2x, g2r
+        got = chain(fn, x0, R, H)
+        want = chain(ref, x0.double(), R.double(), H.double())
+        clamped = which == "rownorm" and shape[0] > 2
+        for name, a, b in zip(("y", "gx", "d2/dx", "d2/dg"), got, want):
+            if clamped and name == "d2/dx":                  # torch's own second derivative is NaN on the zero row; ours is 0
+                assert bool((a[1] == 0).all())
+                a, b = torch.cat([a[:1], a[2:]]), torch.cat([b[:1], b[2:]])
+            assert relerr(a, b) <= 5e-6, (which, shape, name)
+
+
 def test_rowgram_family_first_and_second_derivatives(dev):
     """csrc/lcao_double.hip rowgram / rowmix (the per-edge Gram matrix of lcaonet.py:179-184 and its derivatives): values
     against fp64 einsums, and gradient + gradient-of-gradient through model/double.py's Functions against autograd of

@@ -62,7 +62,7 @@ def main():
     res["c_abi_total_ms"] = round(sum(v[1] for v in ks.values()), 2)
     if args.torch_profile:
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as p:
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as p:
             step()
             torch.cuda.synchronize()
         rows = []
@@ -75,6 +75,14 @@ def main():
                 rows.append((ev.key[:90], ev.count, round(t / 1e3, 3)))
         rows.sort(key=lambda r: -r[2])
         res["torch_device_ms_top"] = rows[:40]
+        by_shape = []
+        for ev in p.key_averages(group_by_input_shape=True):
+            t = getattr(ev, "self_device_time_total", 0)
+            if t and ev.key.startswith("aten::"):
+                by_shape.append((ev.key, str(ev.input_shapes)[:80], ev.count, round(t / 1e3, 3)))
+        by_shape.sort(key=lambda r: -r[3])
+        res["aten_by_shape_top"] = by_shape[:40]
+        res["aten_self_device_ms"] = round(sum(r[3] for r in by_shape), 2)
     s = json.dumps(res, indent=1)
     print(s)
     if args.out:
