@@ -366,6 +366,13 @@ int lcao_trip_weight_bwd2(const float* hc, const float* hG, const float* gw, con
                           const int64_t* tbase, int64_t n_edges, int64_t n_centres, int n_l, float* ggw, float* gc2,
                           float* gG2, void* stream);
 
+/* Radial basis with R' and R'' (second-order jets of the closed forms of lcao_radial_basis): level 0: rb (E, D) -> out_ed;
+ * level 1: out_e[e] = sum_d g[e,d] R_d'(r_e);  level 2 (cotangent h (E) of level 1's output): out_ed[e,d] = h[e] R_d'(r_e),
+ * out_e[e] = h[e] sum_d g[e,d] R_d''(r_e). */
+int lcao_radial_levels(int level, const float* r, const float* g, const float* h, int64_t n_edges, int n_orb,
+                       const float* orb_table, int rbf_kind, int cutoff_kind, float rc, float* out_ed, float* out_e,
+                       void* stream);
+
 /* SiLU and row normalisation (F.normalize, lcaonet.py:196) with closed-form first and second derivatives; `level` selects
  * 0: y(x) -> out0;  1: reverse sweep for cotangent g -> out0;  2: reverse sweep of level 1 for its cotangent h:
  * out0 = d/dg, out1 = d/dx.  Unused inputs / outputs of a level may be NULL. */

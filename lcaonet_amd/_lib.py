@@ -76,6 +76,7 @@ SIGNATURES = {
     "lcao_trip_weight": [P, P, P, P, P, P, P, L, L, I, P, P],
     "lcao_trip_weight_bwd": [P, P, P, P, P, P, P, P, L, L, I, P, P, P],
     "lcao_trip_weight_bwd2": [P, P, P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],
+    "lcao_radial_levels": [I, P, P, P, L, I, P, I, I, F, P, P, P],
     "lcao_silu_levels": [I, P, P, P, L, P, P, P],
     "lcao_rownorm_levels": [I, P, P, P, L, I, F, P, P, P],
     "lcao_rowgram": [P, P, L, I, I, P, P],

@@ -662,6 +662,99 @@ __global__ void k_rownorm_levels(const float* __restrict__ x, const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Radial basis R_d(r) (lcaonet/nn/rbf.py:17-182, cutoff.py:10-67) with R', R'' from one evaluation on second-order jets
+// (value, d/dr, d^2/dr^2):   level 0: rb[e,d] = R_d(r_e)      level 1: gr[e] = sum_d g[e,d] R_d'(r_e)
+//                            level 2 (cotangent h of gr): gg[e,d] = h[e] R_d'(r_e),  gr2[e] = h[e] sum_d g[e,d] R_d''(r_e)
+// Same closed forms as lcao_radial_eval / lcao_cutoff_eval (lcao_common.h): factored envelopes, Horner Laguerre series.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Jet2 {
+  float v, a, b;   // f, f', f''
+  __device__ Jet2() {}
+  __device__ Jet2(float x) : v(x), a(0.f), b(0.f) {}
+  __device__ Jet2(float x, float y, float z) : v(x), a(y), b(z) {}
+};
+__device__ __forceinline__ Jet2 operator+(Jet2 x, Jet2 y) { return Jet2(x.v + y.v, x.a + y.a, x.b + y.b); }
+__device__ __forceinline__ Jet2 operator+(Jet2 x, float y) { return Jet2(x.v + y, x.a, x.b); }
+__device__ __forceinline__ Jet2 operator*(Jet2 x, Jet2 y) {
+  return Jet2(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + 2.0f * x.a * y.a + x.v * y.b);
+}
+__device__ __forceinline__ Jet2 operator*(float x, Jet2 y) { return Jet2(x * y.v, x * y.a, x * y.b); }
+__device__ __forceinline__ Jet2 jet_exp(Jet2 x) {
+  const float e = expf(x.v);
+  return Jet2(e, e * x.a, e * (x.b + x.a * x.a));
+}
+__device__ __forceinline__ Jet2 jet_sin(Jet2 x) {
+  float sn, cs;
+  sincosf(x.v, &sn, &cs);
+  return Jet2(sn, cs * x.a, cs * x.b - sn * x.a * x.a);
+}
+__device__ __forceinline__ Jet2 jet_cos(Jet2 x) {
+  float sn, cs;
+  sincosf(x.v, &sn, &cs);
+  return Jet2(cs, -sn * x.a, -sn * x.b - cs * x.a * x.a);
+}
+__device__ __forceinline__ Jet2 jet_recip(Jet2 x) {
+  const float u = 1.0f / x.v;
+  return Jet2(u, -u * u * x.a, 2.0f * u * u * u * x.a * x.a - u * u * x.b);
+}
+
+__device__ __forceinline__ Jet2 jet_cutoff(Jet2 r, float rc, int kind) {
+  if (kind == LCAO_CUTOFF_NONE) return Jet2(1.0f);
+  if (!(r.v <= rc)) return Jet2(0.0f);
+  const Jet2 x = (1.0f / rc) * r;
+  const Jet2 om = (-1.0f) * x + 1.0f;
+  if (kind == LCAO_CUTOFF_ENVELOPE) {
+    Jet2 q = 15.0f * x + 10.0f;
+    q = q * x + 6.0f;
+    q = q * x + 3.0f;
+    q = q * x + 1.0f;
+    return om * om * om * q;
+  } else if (kind == LCAO_CUTOFF_POLYNOMIAL) {
+    Jet2 q = 6.0f * x + 3.0f;
+    q = q * x + 1.0f;
+    return om * om * om * q;
+  }
+  const Jet2 c = jet_cos(1.57079632679489661923f * x);
+  return c * c;
+}
+
+__device__ __forceinline__ Jet2 jet_radial(Jet2 r, const float* __restrict__ row, int rbf_kind, float rc) {
+  if (rbf_kind == LCAO_RBF_HYDROGEN) {
+    const Jet2 zeta = row[0] * r;
+    const int l = (int)row[2], k = (int)row[3];
+    Jet2 poly(row[4 + k]);
+    for (int i = k - 1; i >= 0; --i) poly = poly * zeta + row[4 + i];
+    Jet2 f = row[1] * poly;
+    for (int i = 0; i < l; ++i) f = f * zeta;
+    return f * jet_exp(-0.5f * zeta);
+  }
+  return jet_sin((row[11] / rc) * r) * jet_recip(r);
+}
+
+template <int LEVEL>
+__global__ void k_radial_levels(const float* __restrict__ r, const float* __restrict__ g, const float* __restrict__ h,
+                                int64_t n_edges, int D, const float* __restrict__ orb_table, int rbf_kind, int cutoff_kind,
+                                float rc, float* __restrict__ o_ed, float* __restrict__ o_e) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const Jet2 rj(r[e], 1.0f, 0.0f);
+  const Jet2 cw = jet_cutoff(rj, rc, cutoff_kind);
+  const float hv = LEVEL == 2 ? h[e] : 0.f;
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const Jet2 f = cw * jet_radial(rj, orb_table + d * LCAO_ORB_STRIDE, rbf_kind, rc);
+    if (LEVEL == 0) o_ed[e * D + d] = f.v;
+    if (LEVEL == 1) acc += g[e * D + d] * f.a;
+    if (LEVEL == 2) {
+      o_ed[e * D + d] = hv * f.a;
+      acc += g[e * D + d] * f.b;
+    }
+  }
+  if (LEVEL == 1) o_e[e] = acc;
+  if (LEVEL == 2) o_e[e] = hv * acc;
+}
+
 static int check_trip(int64_t n_edges, int V, int n_l) {
   if (n_edges < 0 || n_edges >= (int64_t(1) << 31)) return LCAO_ERR_INVALID;
   if (V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
@@ -888,5 +981,27 @@ extern "C" int lcao_rownorm_levels(int level, const float* x, const float* g, co
   else RNL(8);
 #undef RNL
 #undef RN
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_radial_levels(int level, const float* r, const float* g, const float* h, int64_t n_edges, int n_orb,
+                                  const float* orb_table, int rbf_kind, int cutoff_kind, float rc, float* out_ed,
+                                  float* out_e, void* stream) {
+  if (n_edges < 0 || n_orb <= 0 || level < 0 || level > 2) return LCAO_ERR_INVALID;
+  if (rbf_kind != LCAO_RBF_HYDROGEN && rbf_kind != LCAO_RBF_BESSEL) return LCAO_ERR_INVALID;
+  if (cutoff_kind < LCAO_CUTOFF_ENVELOPE || cutoff_kind > LCAO_CUTOFF_NONE) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(r); LCAO_CHECK_PTR(orb_table);
+  if (level != 1) LCAO_CHECK_PTR(out_ed);
+  if (level >= 1) { LCAO_CHECK_PTR(g); LCAO_CHECK_PTR(out_e); }
+  if (level == 2) LCAO_CHECK_PTR(h);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n_edges, 256)), block(256);
+#define RL(LL) hipLaunchKernelGGL(k_radial_levels<LL>, grid, block, 0, st, r, g, h, n_edges, n_orb, orb_table, rbf_kind, \
+                                  cutoff_kind, rc, out_ed, out_e)
+  if (level == 0) RL(0);
+  else if (level == 1) RL(1);
+  else RL(2);
+#undef RL
   return lcao_launch_status();
 }

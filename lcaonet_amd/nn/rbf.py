@@ -89,24 +89,41 @@ class BaseRadialBasis(nn.Module):
         return self._eval(r)
 
     def differentiable(self, r: Tensor) -> Tensor:
-        """The same basis from tensor ops under autograd (any order of derivative) — the (E, D) radial table is tiny
-        next to the (E, V) work, and the exact double backward of force training (model/double.py) needs R, R' and R''."""
-        tab = self.orb_table.to(r.dtype)
-        cw = self.cutoff_net.differentiable(r)
-        cols = []
-        for d in range(tab.shape[0]):
-            row = tab[d]
-            if self.rbf_kind == "hydrogen":
-                zeta = row[0] * r
-                k, l = int(row[3]), int(row[2])
-                poly = torch.full_like(r, float(row[4 + k]))
-                for i in range(k - 1, -1, -1):
-                    poly = poly * zeta + row[4 + i]
-                zl = torch.ones_like(r) if l == 0 else zeta**l
-                cols.append(cw * row[1] * poly * zl * torch.exp(-0.5 * zeta))
-            else:
-                cols.append(cw * torch.sin(row[11] / self.cutoff * r) / r)
-        return torch.stack(cols, dim=1)
+        """The same basis as a twice-differentiable function of r (the exact double backward of force training,
+        model/double.py, needs R, R' and R''): one kernel per derivative level (csrc/lcao_double.hip::k_radial_levels,
+        second-order jets of the closed forms).  A user-defined envelope multiplies the envelope-free basis through its
+        own `differentiable`."""
+        kind = getattr(self.cutoff_net, "kind", None)
+        rb = _RadialFn.apply(r.contiguous(), self.orb_table, self.rbf_kind, kind if kind is not None else "none", self.cutoff)
+        return rb if kind is not None else rb * self.cutoff_net.differentiable(r).unsqueeze(1)
+
+
+class _RadialFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, tab, rbf_kind, cutoff_kind, rc):
+        ctx.args = (tab, rbf_kind, cutoff_kind, rc)
+        ctx.save_for_backward(r)
+        return ops.radial_levels(0, r, *ctx.args)
+
+    @staticmethod
+    def backward(ctx, g):
+        (r,) = ctx.saved_tensors
+        return _RadialBwdFn.apply(g.contiguous(), r, *ctx.args), None, None, None, None
+
+
+class _RadialBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, r, tab, rbf_kind, cutoff_kind, rc):
+        ctx.args = (tab, rbf_kind, cutoff_kind, rc)
+        ctx.save_for_backward(g, r)
+        return ops.radial_levels(1, r, *ctx.args, g=g)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, h):
+        g, r = ctx.saved_tensors
+        gg, gr2 = ops.radial_levels(2, r, *ctx.args, g=g, h=h.contiguous())
+        return gg, gr2, None, None, None, None
 
 
 class HydrogenRadialBasis(BaseRadialBasis):

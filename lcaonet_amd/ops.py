@@ -750,6 +750,25 @@ def trip_weight_bwd2(hc, hG, gw, c, G, geo):
     return ggw, gc2, gG2
 
 
+def radial_levels(level: int, r, orb_table, rbf_kind: str, cutoff_kind: str, rc: float, g=None, h=None):
+    """Radial basis with R', R'' (csrc/lcao_double.hip): level 0 -> rb (E, D); 1 -> gr (E,) = sum_d g R';
+    2 -> (gg (E, D) = h R', gr2 (E,) = h sum_d g R'')."""
+    r, orb_table = _f32(r, "r"), _f32(orb_table, "orb_table")
+    E, D = r.numel(), orb_table.shape[0]
+    g = None if g is None else _f32(g, "g")
+    h = None if h is None else _f32(h, "h")
+    if g is not None and tuple(g.shape) != (E, D):
+        raise ValueError(f"radial_levels: g {tuple(g.shape)} must be ({E}, {D})")
+    if h is not None and h.numel() != E:
+        raise ValueError(f"radial_levels: h {tuple(h.shape)} must have {E} elements")
+    o_ed = torch.empty(E, D, device=r.device, dtype=torch.float32) if level != 1 else None
+    o_e = torch.empty(E, device=r.device, dtype=torch.float32) if level >= 1 else None
+    opt = lambda t: _p(t) if t is not None else None
+    _call("lcao_radial_levels", level, _p(r), opt(g), opt(h), E, D, _p(orb_table), RBF_KINDS[rbf_kind],
+          CUTOFF_KINDS[cutoff_kind], float(rc), opt(o_ed), opt(o_e), _stream())
+    return o_ed if level == 0 else (o_e if level == 1 else (o_ed, o_e))
+
+
 def silu_levels(level: int, x, g=None, h=None):
     """SiLU with closed-form derivatives (csrc/lcao_double.hip): level 0 -> y; 1 -> g s1(x); 2 -> (h s1(x), h g s2(x))."""
     x = _f32(x, "x")

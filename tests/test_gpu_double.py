@@ -229,6 +229,59 @@ def test_pointwise_levels_first_and_second_derivatives(dev, which):
             assert relerr(a, b) <= 5e-6, (which, shape, name)
 
 
+@pytest.mark.parametrize("rbf_type,cutoff_type", [("hydrogen", "envelope"), ("hydrogen", "polynomial"),
+                                                  ("hydrogen", "cosine"), ("sphericalbessel", "envelope"),
+                                                  ("hydrogen", "envelope_p7")])
+def test_radial_levels_first_and_second_derivatives(dev, rbf_type, cutoff_type):
+    """csrc/lcao_double.hip k_radial_levels (R, R', R'' of lcaonet/nn/rbf.py:17-182 with the envelopes of cutoff.py:10-67):
+    value, gradient and gradient-of-gradient against fp64 tensor ops under autograd — the closed forms written out here
+    from the orbital table."""
+    import math
+    from lcaonet_amd.atomistic.info import ElecInfo
+    from lcaonet_amd.nn.cutoff import CosineCutoff, EnvelopeCutoff, PolynomialCutoff
+    from lcaonet_amd.nn.rbf import HydrogenRadialBasis, SphericalBesselRadialBasis
+    rc = 5.0
+    cn = {"envelope": EnvelopeCutoff(rc), "polynomial": PolynomialCutoff(rc), "cosine": CosineCutoff(rc),
+          "envelope_p7": EnvelopeCutoff(rc, 7)}[cutoff_type]
+    ei = ElecInfo(96, None)
+    basis = (HydrogenRadialBasis if rbf_type == "hydrogen" else SphericalBesselRadialBasis)(rc, ei, cn).to(dev)
+    tab = basis.orb_table.double().cpu()
+    D = tab.shape[0]
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    r0 = (0.4 + 4.9 * torch.rand(4001, generator=gen)).to(dev)              # includes r > rc (identically zero there)
+    R, H = torch.randn(4001, D, generator=gen).to(dev), torch.randn(4001, generator=gen).to(dev)
+
+    def ref(r):
+        cols = []
+        for d in range(D):
+            row = [float(v) for v in tab[d]]
+            if rbf_type == "hydrogen":
+                zeta = row[0] * r
+                l, k = int(row[2]), int(row[3])
+                poly = sum(row[4 + i] * zeta**i for i in range(k + 1))
+                cols.append(row[1] * poly * zeta**l * torch.exp(-0.5 * zeta))
+            else:
+                cols.append(torch.sin(row[11] / rc * r) / r)
+        return torch.stack(cols, dim=1) * cn.differentiable(r).unsqueeze(1)
+
+    def chain(f, r, R_, H_):
+        r, R_ = r.clone().requires_grad_(True), R_.clone().requires_grad_(True)
+        rb = f(r)
+        (gr,) = torch.autograd.grad((rb * R_).sum(), r, create_graph=True)
+        g2r, g2g = torch.autograd.grad((gr * H_).sum(), (r, R_))
+        return rb.detach(), gr.detach(), g2r, g2g
+    got = chain(basis.differentiable, r0, R, H)
+    want = chain(ref, r0.double(), R.double(), H.double())
+    # the reverse sums mix orbitals of very different magnitude: compare per orbital for the (E, D) results
+    for name, a, b in zip(("rb", "gr", "d2/dr", "d2/dg"), got, want):
+        if a.dim() == 2:
+            for d in range(D):
+                assert relerr(a[:, d], b[:, d]) <= 2e-5, (name, d, relerr(a[:, d], b[:, d]))
+        else:
+            assert relerr(a, b) <= 2e-5, (name, relerr(a, b))
+    assert math.isfinite(float(got[2].abs().max()))
+
+
 def test_rowgram_family_first_and_second_derivatives(dev):
     """csrc/lcao_double.hip rowgram / rowmix (the per-edge Gram matrix of lcaonet.py:179-184 and its derivatives): values
     against fp64 einsums, and gradient + gradient-of-gradient through model/double.py's Functions against autograd of
