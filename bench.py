@@ -375,7 +375,7 @@ def main():
             return 1e3 * (time.perf_counter() - t1) / args.steps, err
 
     secondary_error = None
-    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = mat_ms = mat_err = h_ms = h_err = None
+    pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = ftrain_ms = mat_ms = mat_err = h_ms = h_err = None
     kall = {}
     if rank == 0:
         try:
@@ -422,6 +422,26 @@ def main():
                 torch.cuda.synchronize()
                 train_ms = 1e3 * (time.perf_counter() - t1) / max(args.steps // 4, 2)
                 del tm, opt
+                # training ON FORCES: energy + exact autograd forces (create_graph) + backward through the force graph
+                ftm = build_model(dict(model_kw, regress_forces=True, direct_forces=False), 1234, dev).train()
+                fopt = torch.optim.Adam(ftm.parameters(), lr=1e-4)
+                f_target = torch.zeros(N, 3, device=dev)
+
+                def force_train_step():
+                    fopt.zero_grad(set_to_none=True)
+                    e_pred, f_pred = ftm(batch)
+                    (torch.nn.functional.l1_loss(e_pred, target) + torch.nn.functional.l1_loss(f_pred, f_target)).backward()
+                    fopt.step()
+
+                force_train_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    force_train_step()
+                torch.cuda.synchronize()
+                ftrain_ms = 1e3 * (time.perf_counter() - t1) / 2
+                del ftm, fopt
+                torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             secondary_error = f"{type(e).__name__}: {e}"
 
@@ -540,6 +560,12 @@ def main():
             line["training_step_mode"] = {
                 "note": "NOT the headline: train mode, forward + HIP backward (all parameter gradients) + Adam step",
                 "ms_per_step_rank0": round(train_ms, 3), "edges_per_s_rank0": E / (train_ms * 1e-3)}
+        if ftrain_ms is not None:
+            line["force_training_step_mode"] = {
+                "note": "NOT the headline: train mode, regress_forces=True, direct_forces=False — energy, exact autograd forces "
+                        "(create_graph), L1 loss on both, backward through the force graph (twice-differentiable HIP "
+                        "primitives, model/double.py) + Adam step",
+                "ms_per_step_rank0": round(ftrain_ms, 3), "edges_per_s_rank0": E / (ftrain_ms * 1e-3)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
