@@ -14,13 +14,17 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 //   LCAO_ABL & 8: WITHOUT the s_setprio(1) around each layer's MFMA stream     & 16: static s_setprio(1) for waves 4-7
 //   LCAO_ABL & 128 / & 256 / & 512 (k_triplet_bwd_mfma): GEMM 1 cut to one k chunk / no scalar chain / GEMM 2 cut to one tile
 //   LCAO_ABL & 32 / & 64 (k_triplet_gemm, tools/k3_ablate.py): no Y_l / norm arithmetic / one MFMA per in-edge step
+//   LCAO_ABL & 1024 / & 2048 / & 4096 (k_edge_node_message_agg, tools/k4b_ablate.py): no segmented reduction / identity
+//   activations / target rows gathered from the centre's own row (no random gather)
 #ifndef LCAO_ABL
 #define LCAO_ABL 0
 #endif
 #if LCAO_ABL & 1
 #define K2_ACT(x) (x)
+#define K2_ACT4(x) (x)
 #else
 #define K2_ACT(x) lcao_silu_log2e(x)
+#define K2_ACT4(x) lcao_silu_log2e4(x)
 #endif
 
 #define LCAO_LOG2E 1.44269504088896340736f
@@ -29,6 +33,19 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // g(x') = x' / (1 + 2^(-x')) = SiLU(x) log2 e for x' = x log2 e: v_exp_f32 (negated source), v_add, v_rcp_f32, v_mul
 __device__ __forceinline__ float lcao_silu_log2e(float xs) {
   return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-xs));
+}
+
+// the same on four accumulator values with the add and the multiply as vector ops (v_pk_add_f32 / v_pk_mul_f32: two
+// lanes' worth per instruction): the fp32 MFMA stream and VALU instructions share the SIMD's vector issue
+// (profiles/r02/mfma_valu_overlap.txt: t(both) = t(mfma) + t(valu)), so every VALU instruction saved is kernel time.
+__device__ __forceinline__ f32x4v lcao_silu_log2e4(f32x4v xs) {
+  f32x4v e;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(-xs[j]);
+  e = e + 1.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
+  return xs * e;
 }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)

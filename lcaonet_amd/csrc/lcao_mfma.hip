@@ -248,9 +248,7 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
         for (int a = 0; a < KT1; ++a) x[a] = *(const f32x4v*)(xrow + (d + 1) * C + 16 * a);
       }
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h[m][j] = K2_ACT(h[m][j]);
+      for (int m = 0; m < MT; ++m) h[m] = K2_ACT4(h[m]);
       f32x4v o[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -268,9 +266,7 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
       for (int ll = 0; ll < NL; ++ll) {
         if (l == ll) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ll][m][j] += w * K2_ACT(o[m][j]);
+          for (int m = 0; m < MT; ++m) acc[ll][m] += w * K2_ACT4(o[m]);
         }
       }
     }
@@ -681,14 +677,14 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
     for (int a = 0; a < MT; ++a) {
       f32x4v sv = *(const f32x4v*)(ps + 16 * a) + *(const f32x4v*)(pt + 16 * a);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) h[a][j] = lcao_silu(sv[j]);
+      for (int j = 0; j < 4; ++j) h[a][j] = (LCAO_ABL & 2048) ? sv[j] : lcao_silu(sv[j]);
     }
     npb = pb + 16; npend = pend; nhave = true;
     if (npb >= pend) { nchunk = chunk + cstride; nhave = seek(nchunk, npb, npend); }
     if (nhave) {
       const int pn = min(npb + r, npend - 1);
       s_nxt = src_p[pn];
-      d_nxt = dst_p[pn];
+      d_nxt = (LCAO_ABL & 4096) ? s_nxt : dst_p[pn];
     }
   }
   while (have) {
@@ -712,7 +708,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
       if (n2have) {
         const int pn2 = min(n2pb + r, n2pend - 1);
         s_n2 = src_p[pn2];
-        d_n2 = dst_p[pn2];
+        d_n2 = (LCAO_ABL & 4096) ? s_n2 : dst_p[pn2];
       }
     }
     f32x4v o[MT], wv[MT];
@@ -727,7 +723,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[m][j] = valid ? wv[m][j] * lcao_silu(o[m][j]) : 0.f;   // message rows; 0 past the chunk
+      for (int j = 0; j < 4; ++j) o[m][j] = valid ? wv[m][j] * ((LCAO_ABL & 2048) ? o[m][j] : lcao_silu(o[m][j])) : 0.f;   // message rows; 0 past the chunk
     // segmented sum over the 16 edges of the tile, segment by segment (wave-uniform loop over the segment heads found by
     // a ballot; 1-3 per tile).  Only the first segment can continue a node from the previous tile and only the last can
     // continue into the next: their node bounds come from two vector loads issued before the GEMM (eb / ee), so the
@@ -739,6 +735,13 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
     const int first_beg = __builtin_amdgcn_readfirstlane(eb);
     const int last_end = __builtin_amdgcn_readlane(ee, n_valid - 1);
     unsigned rem = (unsigned)heads;
+    if (LCAO_ABL & 1024) {   // ablation: no segmented reduction (one guarded store keeps the GEMM alive)
+      rem = 0;
+      float chk = (float)(first_beg + last_end);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) chk += o[m][0] + o[m][1] + o[m][2] + o[m][3];
+      if (chk == 12345.678f) agg[lane] = chk;
+    }
     while (rem) {
       const int a = __builtin_ctz(rem);
       rem &= rem - 1;
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
       for (int a = 0; a < MT; ++a) {
         f32x4v sv = ns[a] + nt[a];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h[a][j] = lcao_silu(sv[j]);
+        for (int j = 0; j < 4; ++j) h[a][j] = (LCAO_ABL & 2048) ? sv[j] : lcao_silu(sv[j]);
       }
     }
     have = nhave; chunk = nchunk; pb = npb; pend = npend; s_cur = s_nxt;

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--n-cells", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--torch-profile", action="store_true")
+    ap.add_argument("--mode", default="forces", choices=["forces", "energy", "infer-forces"],
+                    help="forces: train on energy + autograd forces; energy: train on energy only; infer-forces: eval, no grad")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -32,15 +34,23 @@ def main():
     batch = jittered_cubic_cells(seed=1234, device=dev, **gen_kw)
     E = int(batch["edge_index"].shape[1])
     N = int(batch["z"].numel())
-    m = bench.build_model(dict(model_kw, regress_forces=True, direct_forces=False), 1234, dev).train()
+    forces = args.mode != "energy"
+    m = bench.build_model(dict(model_kw, regress_forces=forces, direct_forces=False) if forces else model_kw, 1234, dev)
+    m = m.eval() if args.mode == "infer-forces" else m.train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     e_t = torch.zeros(args.n_cells, 1, device=dev)
     f_t = torch.zeros(N, 3, device=dev)
 
     def step():
+        if args.mode == "infer-forces":
+            with torch.no_grad():
+                return m(batch)
         opt.zero_grad(set_to_none=True)
-        e, f = m(batch)
-        loss = torch.nn.functional.l1_loss(e, e_t) + torch.nn.functional.l1_loss(f, f_t)
+        if forces:
+            e, f = m(batch)
+            loss = torch.nn.functional.l1_loss(e, e_t) + torch.nn.functional.l1_loss(f, f_t)
+        else:
+            loss = torch.nn.functional.l1_loss(m(batch), e_t)
         loss.backward()
         opt.step()
         return loss
