@@ -13,7 +13,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 //   LCAO_ABL & 4: weight fragments read once per feature-tile pair instead of once per k chunk (1/KT of the LDS reads)
 //   LCAO_ABL & 8: WITHOUT the s_setprio(1) around each layer's MFMA stream     & 16: static s_setprio(1) for waves 4-7
 //   LCAO_ABL & 128 / & 256 / & 512 (k_triplet_bwd_mfma): GEMM 1 cut to one k chunk / no scalar chain / GEMM 2 cut to one tile
-//   LCAO_ABL & 32 / & 64 (k_triplet_gemm, tools/k3_ablate.py): no Y_l / norm arithmetic / one MFMA per in-edge step
+//   LCAO_ABL & 64 (k_triplet_gemm, tools/k3_ablate.py): one MFMA per in-edge step
 //   LCAO_ABL & 1024 / & 2048 / & 4096 (k_edge_node_message_agg, tools/k4b_ablate.py): no segmented reduction / identity
 //   activations / target rows gathered from the centre's own row (no random gather)
 #ifndef LCAO_ABL

@@ -1101,30 +1101,46 @@ __device__ __forceinline__ int gram_idx(int l, int l2) {  // l <= l2, row-major 
   return l * 4 - (l * (l - 1)) / 2 + (l2 - l);
 }
 
+// Per-triplet weights of the two 16-wide out-edge tiles of a step at once (packed fp32: .x = tile A, .y = tile B).
+// Monic angular polynomials y0' = 1, y1' = c, y2' = c^2 - Y2B/Y2A, y3' = c (c^2 - 3/5) with Y_l = s_l y_l'; the Gram
+// entries arrive PRE-SCALED, g[l,l'] = m s_l s_l' G[l,l'] (m = 2 off the diagonal; the scale is one per-lane multiply on
+// the loaded word), so  n2 = sum_{l<=l'} g[l,l'] y_l' y_l''  is a chain of packed FMAs, and the lane's own Y_quarter comes
+// from per-lane constants k_l = s_l [l == quarter] instead of a select.  ~21 VALU instructions for both weights (the
+// scalar version took ~40 each, more cycles than the 16 MFMAs they feed: fp32 MFMA and VALU share the SIMD's issue).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+#define LCAO_Y2_SHIFT (0.31539156525252f / 0.94617469575756f)
+__host__ __device__ constexpr float trip_scale(int l) {   // s_l
+  return l == 0 ? 0.28209479177387814f : l == 1 ? 0.48860251190292f : l == 2 ? 0.94617469575756f : 5.0f * 0.373176332590115f;
+}
+
 template <int NL>
-__device__ __forceinline__ float triplet_weight(float ux, float uy, float uz, float qx, float qy, float qz,
-                                                const float (&G)[10], int quarter, bool ok) {
-#if LCAO_ABL & 32
-  return ok ? (ux * qx + G[0] * (float)quarter) : 0.f;   // diagnostic: no Y_l / norm arithmetic
-#endif
-  const float c = ux * qx + uy * qy + uz * qz;
-  float y[4];
-  y[0] = lcao_y_l0(c, 0);
-  y[1] = lcao_y_l0(c, 1);
-  y[2] = lcao_y_l0(c, 2);
-  y[3] = lcao_y_l0(c, 3);
-  float n2 = 0.f;
-#pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    n2 += y[l] * y[l] * G[gram_idx(l, l)];
-#pragma unroll
-    for (int l2 = l + 1; l2 < NL; ++l2) n2 += 2.0f * (y[l] * y[l2]) * G[gram_idx(l, l2)];
+__device__ __forceinline__ f32x2v triplet_weight2(f32x2v ux, f32x2v uy, f32x2v uz, float qx, float qy, float qz,
+                                                  const float (&g)[10], const float (&k)[4], bool okA, bool okB) {
+  const f32x2v c = ux * qx + uy * qy + uz * qz;
+  f32x2v n2 = {g[gram_idx(0, 0)], g[gram_idx(0, 0)]};
+  f32x2v yq = {k[0], k[0]};
+  f32x2v c2, y2;
+  if (NL > 1) {
+    c2 = c * c;
+    n2 += g[gram_idx(0, 1)] * c + g[gram_idx(1, 1)] * c2;
+    yq += k[1] * c;
   }
-  // 1 / max(sqrt(n2), 1e-12) = rsqrt(max(n2, 1e-24)): one v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide
-  // sequences (~40 VALU per weight, more than the MFMAs each weight feeds)
-  const float inv = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));
-  const float yq = quarter == 0 ? y[0] : (quarter == 1 ? y[1] : (quarter == 2 ? y[2] : y[3]));
-  return ok ? yq * inv : 0.f;
+  if (NL > 2) {
+    y2 = c2 - LCAO_Y2_SHIFT;
+    n2 += g[gram_idx(0, 2)] * y2 + g[gram_idx(1, 2)] * (c * y2) + g[gram_idx(2, 2)] * (y2 * y2);
+    yq += k[2] * y2;
+  }
+  if (NL > 3) {
+    const f32x2v y3 = c * (c2 - 0.6f);
+    n2 += g[gram_idx(0, 3)] * y3 + g[gram_idx(1, 3)] * (c * y3) + g[gram_idx(2, 3)] * (y2 * y3) + g[gram_idx(3, 3)] * (y3 * y3);
+    yq += k[3] * y3;
+  }
+  // 1 / max(sqrt(n2), 1e-12) = rsqrt(max(n2, 1e-24)): one v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequences
+  f32x2v w = {__builtin_amdgcn_rsqf(fmaxf(n2[0], 1e-24f)), __builtin_amdgcn_rsqf(fmaxf(n2[1], 1e-24f))};
+  w *= yq;
+  w[0] = okA ? w[0] : 0.f;
+  w[1] = okB ? w[1] : 0.f;
+  return w;
 }
 
 template <int V, int NL>
@@ -1138,28 +1154,76 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, quarter = lane >> 4;
-  const bool frag_ok0 = quarter < NL;
 
   // One step = one in-edge q.  Everything a step needs arrives through the VECTOR memory pipe, PD steps ahead:
   //   F[h]: this lane's 16-B pieces of Ag[q, quarter, :]          (2 x global_load_dwordx4)
   //   R   : lane i < 3 holds u_q[i], lane 3 + i holds gram[q, i]  (1 x global_load_dword, then v_readlane)
-  // VMEM returns in order, so the compiler's counted vmcnt leaves the later steps in flight while step j is consumed;
-  // scalar (SMEM) loads would force lgkmcnt(0) on every use and sat on the critical path of each step.
+  // VMEM returns in order, so a COUNTED s_waitcnt vmcnt((PD-1) x 3) leaves the later steps in flight while step j is
+  // consumed — but the compiler can only count if every step issues exactly the same loads.  So nothing here is
+  // conditional: lanes of quarter >= n_l read the row of the last real l (their weight is forced to zero instead), the
+  // u / gram word is one load through a per-lane pointer, and a refill past the node's last in-edge re-reads that last
+  // row (an L1 hit).  With any of these under a branch hipcc emitted vmcnt(0) at every step, i.e. a one-step prefetch.
+  // Scalar (SMEM) loads would force lgkmcnt(0) on every use and sat on the critical path of each step.
+  constexpr int QL = NL - 1;
+  const int qrow = quarter < NL ? quarter : QL;
+  // per-lane constants: the scale of this lane's loaded word (lanes 3..12 hold gram entry lane - 3 = (l, l') in upper-
+  // triangle order) and the one-hot Y_quarter coefficients
+  float rscale = 1.0f;
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+#pragma unroll
+    for (int l2 = l; l2 < 4; ++l2)
+      if (lane - 3 == gram_idx(l, l2)) rscale = (l == l2 ? 1.0f : 2.0f) * trip_scale(l) * trip_scale(l2);
+  float kq[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) kq[l] = (quarter == l && l < NL) ? trip_scale(l) : 0.f;
   auto load_step = [&](f32x4v(&F)[HG], float& R, int q) {
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
-      F[h] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      if (frag_ok0 && (64 * h + 4 * n) < V) F[h] = *(const f32x4v*)(Ag + ((int64_t)q * NL + quarter) * V + 64 * h + 4 * n);
+      const int ch = (64 * h + 4 * n) < V ? 64 * h + 4 * n : 0;
+      F[h] = *(const f32x4v*)(Ag + ((int64_t)q * NL + qrow) * V + ch);
     }
-    R = 0.f;
-    if (lane < 3) R = uvec_p[3 * (int64_t)q + lane];
-    else if (lane < 13) R = gram[10 * (int64_t)q + (lane - 3)];
+    const float* rp = lane < 3 ? uvec_p + 3 * (int64_t)q + lane : gram + 10 * (int64_t)q + min(lane - 3, 9);
+    R = *rp * rscale;
+  };
+  auto step = [&](f32x4v(&F)[HG], float R, int q0, f32x2v ux, f32x2v uy, f32x2v uz, int pA, int pB, bool vA, bool vB, bool two,
+                  f32x4v(&acc)[2][HG][4]) {
+    const int r0i = __float_as_int(R);  // readlane moves raw 32-bit lanes
+    const float qx = __int_as_float(__builtin_amdgcn_readlane(r0i, 0)),
+                qy = __int_as_float(__builtin_amdgcn_readlane(r0i, 1)),
+                qz = __int_as_float(__builtin_amdgcn_readlane(r0i, 2));
+    float G[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) G[k] = 0.f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int l2 = l; l2 < NL; ++l2)
+        G[gram_idx(l, l2)] = __int_as_float(__builtin_amdgcn_readlane(r0i, 3 + gram_idx(l, l2)));
+    // lcaonet.py:470 drops only the triplet whose two edges coincide (q == p); the back-triplet stays
+    const f32x2v w = triplet_weight2<NL>(ux, uy, uz, qx, qy, qz, G, kq, vA && q0 != pA, vB && q0 != pB);
+#if LCAO_ABL & 64
+    acc[0][0][0] = MFMA16(F[0][0] + F[HG - 1][3] + F[0][1] + F[HG - 1][2], w[0], acc[0][0][0]);  // diagnostic: 1 MFMA per step
+    if (two) acc[1][0][0] = MFMA16(F[0][0], w[1], acc[1][0][0]);
+#else
+#pragma unroll
+    for (int h = 0; h < HG; ++h)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[0][h][jj] = MFMA16(F[h][jj], w[0], acc[0][h][jj]);
+    if (two) {
+#pragma unroll
+      for (int h = 0; h < HG; ++h)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[1][h][jj] = MFMA16(F[h][jj], w[1], acc[1][h][jj]);
+    }
+#endif
   };
 
   // PD steps stay in flight per wave (PD x 1.5 KB at V=128, n_l=3): with 3 waves per SIMD that is ~100 KB of loads in
-  // flight per CU, what a random row gather needs to approach the HBM rate (one-step-ahead prefetch held 30 KB in
-  // flight and stalled 59 % of wave time in s_waitcnt).  Slots are indexed statically (the step loop is unrolled by PD).
-  constexpr int PD = 6;
+  // flight per CU, what a random row gather needs to approach the HBM rate.  Slots are indexed statically (the step loop
+  // is unrolled by PD): full groups of PD steps first — every step consumes its slot and refills it —, then the < PD
+  // remaining steps without refills.
+  constexpr int PD = 5;
   for (int s = blockIdx.x * 4 + wave; s < n_nodes; s += gridDim.x * 4) {
     const int p0 = out_ptr[s], p1 = out_ptr[s + 1];
     const int j0 = in_ptr[s];
@@ -1170,8 +1234,7 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
       const bool two = (p1 - pb) > 16;  // wave-uniform
       const float* ua = uvec_p + 3 * (int64_t)(vA ? pA : p0);
       const float* ub = uvec_p + 3 * (int64_t)(vB ? pB : p0);
-      const float uax = ua[0], uay = ua[1], uaz = ua[2];
-      const float ubx = ub[0], uby = ub[1], ubz = ub[2];
+      const f32x2v ux = {ua[0], ub[0]}, uy = {ua[1], ub[1]}, uz = {ua[2], ub[2]};
       f32x4v acc[2][HG][4];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1189,55 +1252,21 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < PD; ++i) {
           Q[i] = __builtin_amdgcn_readlane(idv, min(i, cn - 1));
-          if (i < cn) load_step(F[i], R[i], Q[i]);
+          load_step(F[i], R[i], Q[i]);
         }
-        for (int jb = 0; jb < cn; jb += PD) {
+        int jb = 0;
+        for (; jb + PD <= cn; jb += PD) {
 #pragma unroll
           for (int i = 0; i < PD; ++i) {
-            const int j = jb + i;
-            if (j < cn) {  // wave-uniform
-              const int q0 = Q[i];
-              const int r0i = __float_as_int(R[i]);  // readlane moves raw 32-bit lanes
-              const float qx = __int_as_float(__builtin_amdgcn_readlane(r0i, 0)),
-                          qy = __int_as_float(__builtin_amdgcn_readlane(r0i, 1)),
-                          qz = __int_as_float(__builtin_amdgcn_readlane(r0i, 2));
-              float G[10];
-#pragma unroll
-              for (int k = 0; k < 10; ++k) G[k] = 0.f;
-#pragma unroll
-              for (int l = 0; l < NL; ++l)
-#pragma unroll
-                for (int l2 = l; l2 < NL; ++l2)
-                  G[gram_idx(l, l2)] = __int_as_float(__builtin_amdgcn_readlane(r0i, 3 + gram_idx(l, l2)));
-              // lcaonet.py:470 drops only the triplet whose two edges coincide (q == p); the back-triplet stays
-              const float wA = triplet_weight<NL>(uax, uay, uaz, qx, qy, qz, G, quarter, vA && q0 != pA);
-#if LCAO_ABL & 64
-              acc[0][0][0] = MFMA16(F[i][0][0] + F[i][HG - 1][3] + F[i][0][1] + F[i][HG - 1][2], wA, acc[0][0][0]);  // diagnostic: 1 MFMA per step
-#else
-#pragma unroll
-              for (int h = 0; h < HG; ++h)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[0][h][jj] = MFMA16(F[i][h][jj], wA, acc[0][h][jj]);
-#endif
-              if (two) {
-                const float wB = triplet_weight<NL>(ubx, uby, ubz, qx, qy, qz, G, quarter, vB && q0 != pB);
-#if LCAO_ABL & 64
-                acc[1][0][0] = MFMA16(F[i][0][0], wB, acc[1][0][0]);
-#else
-#pragma unroll
-                for (int h = 0; h < HG; ++h)
-#pragma unroll
-                  for (int jj = 0; jj < 4; ++jj) acc[1][h][jj] = MFMA16(F[i][h][jj], wB, acc[1][h][jj]);
-#endif
-              }
-              // refill this slot with step j + PD
-              if (j + PD < cn) {
-                Q[i] = __builtin_amdgcn_readlane(idv, j + PD);
-                load_step(F[i], R[i], Q[i]);
-              }
-            }
+            step(F[i], R[i], Q[i], ux, uy, uz, pA, pB, vA, vB, two, acc);
+            Q[i] = __builtin_amdgcn_readlane(idv, min(jb + i + PD, cn - 1));   // refill this slot with step j + PD
+            load_step(F[i], R[i], Q[i]);
           }
         }
+        const int rem = cn - jb;
+#pragma unroll
+        for (int i = 0; i < PD - 1; ++i)
+          if (i < rem) step(F[i], R[i], Q[i], ux, uy, uz, pA, pB, vA, vB, two, acc);   // wave-uniform
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {

@@ -25,7 +25,8 @@ for path in sorted(glob.glob(sys.argv[1] + "/lib*.so")):
     lib = ctypes.CDLL(path)
     fn = lib.lcao_triplet_gemm
     fn.argtypes = _lib.SIGNATURES["lcao_triplet_gemm"]
-    run = lambda: fn(p(Ag), p(gram10), p(u), p(ctx.in_ptr), p(ctx.in_pos), p(ctx.out_ptr), N, E, V, NL, p(tbw), None)
+    in_pos = ctx.in_pos if not os.environ.get("K3_CONTIG") else torch.arange(E, device=dev, dtype=torch.int32)  # in-order Ag layout
+    run = lambda: fn(p(Ag), p(gram10), p(u), p(ctx.in_ptr), p(in_pos), p(ctx.out_ptr), N, E, V, NL, p(tbw), None)
     for _ in range(3): assert run() == 0
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
