@@ -192,7 +192,9 @@ int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* or
                             const float* W2, const float* gate /* (N,V) sigmoid(xk), nullable */,
                             const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, int valence,
                             float* A, float* B, float* Bv, float* Ag, float* gram,
-                            void* workspace /* device, >= 8 bytes: tile-queue counters, zeroed by the call */,
+                            void* workspace /* device, >= 16 bytes, ZERO on first use: the kernels' tile queue; every launch
+                                               leaves it zero again (no memset is issued); launches sharing one
+                                               workspace must be ordered (same stream) */,
                             size_t ws_bytes, void* stream);
 
 /* cst_row for the call above when cst is LCAOEmbedding's species-pair table: row[p] = z[src_p[p]] * zdim + z[dst_p[p]]
@@ -202,7 +204,7 @@ int lcao_pair_rows(const int64_t* z, const int32_t* src_p, const int32_t* dst_p,
 
 /* BASELINE config 3: the same fused kernel with both Dense layers on bf16 MFMA, every fp32 operand split into two
  * bf16 terms and each product run as three MFMAs with fp32 accumulation ("bf16x3": 6-9e-6 relative error on the MLP,
- * against 3.6e-3 for plain bf16).  No valence.  workspace >= 4 bytes. */
+ * against 3.6e-3 for plain bf16).  No valence.  workspace >= 8 bytes, zero on first use (as above). */
 int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
                                    const int32_t* l_of_d, const float* W1, const float* W2, const float* gate, const int32_t* src_p,
                                    int64_t n_edges, int n_orb, int C, int V, int n_l, float* A, float* B, float* Ag,

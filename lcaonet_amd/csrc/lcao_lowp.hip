@@ -238,6 +238,7 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_lowp(
     if (lane == 0) nxt = atomicAdd(tile_counter, 1u);
     tile = first_dynamic + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
   }
+  if (lane == 0) lcao_tile_queue_leave(tile_counter, gridDim.x * (THREADS / 64));   // the last wave re-arms the queue
 }
 
 template <int PREC, int C, int V, int NL>
@@ -260,8 +261,6 @@ static int launch_coeff_mlp_lowp(const float* cst, const float* rb, const int32_
   int64_t groups = (tiles + WAVES - 1) / WAVES;
   int64_t cap = (int64_t)lcao_num_cu() * ((lds > 80 * 1024) ? 1 : 2);
   if (groups > cap) groups = cap;
-  hipError_t me = hipMemsetAsync(counter, 0, sizeof(unsigned), st);
-  if (me != hipSuccess) return int(me);
   hipLaunchKernelGGL((k_coeff_mlp_lowp<PREC, C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb,
                      order, cst_row, l_of_d, W1, W2, E, D, A, Bout, gate, src_p, Ag, gram, counter);
   return lcao_launch_status();
@@ -278,7 +277,7 @@ static int coeff_mlp_contract_lowp(const float* cst, const float* rb, const int3
   LCAO_CHECK_PTR(cst); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(W1); LCAO_CHECK_PTR(W2);
   LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(workspace);
   if (Ag) { LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(gram); } else { LCAO_CHECK_PTR(A); }
-  if (ws_bytes < sizeof(unsigned)) return LCAO_ERR_INVALID;
+  if (ws_bytes < 2 * sizeof(unsigned)) return LCAO_ERR_INVALID;   // {drawn, left} of the tile queue
   hipStream_t st = (hipStream_t)stream;
   unsigned* ctr = (unsigned*)workspace;
 #define LP_CASE(C_, V_, NL_)                                                                                       \

@@ -127,6 +127,17 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ wl, int ldw
   }
 }
 
+// Tile queue of the persistent coefficient kernels: q[0] = tiles drawn, q[1] = waves that have left.  Both are zero
+// before the first launch (the caller allocates the workspace zeroed, once); every wave calls this after its last draw and
+// the last of `total_waves` re-arms the queue, so the words are zero again when the kernel ends.  Launches that share a
+// workspace must be ordered (same stream).
+__device__ __forceinline__ void lcao_tile_queue_leave(unsigned* q, unsigned total_waves) {
+  if (atomicAdd(q + 1, 1u) == total_waves - 1) {
+    atomicExch(q, 0u);
+    atomicExch(q + 1, 0u);
+  }
+}
+
 template <typename KernelT>
 static int set_lds_attr(KernelT kern, size_t lds, bool& done) {
   if (!done) {

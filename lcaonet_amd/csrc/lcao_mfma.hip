@@ -190,7 +190,9 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
     r0 = __builtin_amdgcn_s_memrealtime();
   }
   // Dynamic tile queue: the first tile of a wave is static, every further one is drawn from a device-scope
-  // counter (zeroed by the launcher).  With a static split the two waves that share a SIMD finished 1.5 ms apart
+  // counter.  The queue re-arms ITSELF (lcao_tile_queue_leave: the last wave to leave zeroes it), so a launch needs no
+  // memset before it: hipMemsetAsync nodes in a captured HIP graph proved unreliable for this (profiles/r02/
+  // graph_replay_tile_queue.txt: replays at sizes with dynamic tiles lost them or faulted; static striding never did).  With a static split the two waves that share a SIMD finished 1.5 ms apart
   // (the older wave wins MFMA arbitration, completes its share early and leaves the other to run alone);
   // drawing tiles keeps both resident until the queue is empty.  Every wave exits once it draws tile >= n_tiles.
 #if LCAO_ABL & 16
@@ -331,10 +333,16 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
         }
       }
     }
+    if (!tile_counter) {   // static striding (LCAO_K2_STATIC=1: diagnostic)
+      tile += first_dynamic;
+      continue;
+    }
     unsigned nxt = 0;
     if (lane == 0) nxt = atomicAdd(tile_counter, 1u);
     tile = first_dynamic + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
   }
+  // every wave passes here exactly once, after its last draw: the last one re-arms the queue for the next launch
+  if (tile_counter && lane == 0) lcao_tile_queue_leave(tile_counter, gridDim.x * WAVES);
   if (clk && lane == 0) {
     unsigned long long* o = clk + 4 * ((size_t)blockIdx.x * WAVES + wave);
     o[0] = __builtin_amdgcn_s_memtime() - t0;
@@ -376,8 +384,9 @@ static int launch_coeff_mlp_t(const float* cst, const float* rb, const int32_t* 
   int64_t per_cu = (lds > 80 * 1024) ? 1 : 2;
   int64_t cap = (int64_t)lcao_num_cu() * per_cu;
   if (groups > cap) groups = cap;
-  hipError_t me = hipMemsetAsync(counter, 0, sizeof(unsigned), st);  // re-armed on every call, stream-ordered
-  if (me != hipSuccess) return int(me);
+  static int k2_static = -1;
+  if (k2_static < 0) { const char* e_ = getenv("LCAO_K2_STATIC"); k2_static = (e_ && atoi(e_)) ? 1 : 0; }
+  if (k2_static) counter = nullptr;   // diagnostic: static striding, no queue
   hipLaunchKernelGGL((k_coeff_mlp<C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb, order,
                      cst_row, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, g_clock_probe);
   return lcao_launch_status();
@@ -428,7 +437,7 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
   if (valence) { LCAO_CHECK_PTR(valence_ed); LCAO_CHECK_PTR(Bv); LCAO_CHECK_PTR(A); }
   if (Ag) { LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(gram); } else { LCAO_CHECK_PTR(A); }
   LCAO_CHECK_PTR(workspace);
-  if (ws_bytes < 2 * sizeof(unsigned)) return LCAO_ERR_INVALID;  // one tile-queue counter per pass
+  if (ws_bytes < 4 * sizeof(unsigned)) return LCAO_ERR_INVALID;  // {drawn, left} per pass (lcao_tile_queue_leave)
   unsigned* ctr = (unsigned*)workspace;
   hipStream_t st = (hipStream_t)stream;
   int rc = LCAO_ERR_UNSUPPORTED;
@@ -443,7 +452,7 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
                                        B, nullptr, nullptr, nullptr, nullptr, ctr, st);                            \
     if (rc != LCAO_OK) return rc;                                                                                  \
     return dispatch_coeff_mlp_nl<C_, V_>(n_l, cst, rb, order, cst_row, l_of_d, valence_ed, W1, W2 + (size_t)V_ * V_, \
-                                         n_edges, n_orb, 1, A, Bv, gate, src_p, Ag, Ag ? gram : nullptr, ctr + 1,  \
+                                         n_edges, n_orb, 1, A, Bv, gate, src_p, Ag, Ag ? gram : nullptr, ctr + 2,  \
                                          st);                                                                      \
   }
   CM_CASE(128, 128)

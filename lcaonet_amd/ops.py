@@ -356,9 +356,9 @@ def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, sr
     gram = torch.empty(E, 10, device=dev, dtype=torch.float32) if gated else None
     if gated:
         gate = _f32(gate, "gate")
-    ws = torch.empty(2, device=dev, dtype=torch.int32)
+    ws = tile_queue_workspace(dev)
     _call("lcao_coeff_mlp_contract_" + precision, _p(cst), _p(rb), _p(order), _p(cst_row), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
-          D, C, V, n_l, _p(A), _p(B), _p(Ag), _p(gram), _p(ws), 8, _stream())
+          D, C, V, n_l, _p(A), _p(B), _p(Ag), _p(gram), _p(ws), 16, _stream())
     return (Ag if gated else A), gram, B, None
 
 
@@ -387,10 +387,10 @@ def coeff_mlp_contract(cst, rb, order, l_of_d, valence_ed, W1, W2, n_l, valence,
         sl = lambda t: None if t is None else t[p0:p1]
         if order is None and p0 != 0:
             raise ValueError("coeff_mlp_contract: a p-range needs the order array")
-        ws = torch.empty(2, device=dev, dtype=torch.int32)  # tile-queue counters (the library zeroes them on the stream)
+        ws = tile_queue_workspace(dev)
         _call("lcao_coeff_mlp_contract", _p(cst), _p(rb), _p(sl(order)), _p(sl(cst_row)), _p(l_of_d), _p(valence_ed), _p(W1), _p(W2),
               _p(gate), _p(sl(src_p)), p1 - p0, D, C, V, n_l, int(valence), _p(sl(A)), _p(sl(B)), _p(sl(Bv)), _p(sl(Ag)),
-              _p(sl(gram)), _p(ws), 8, _stream())
+              _p(sl(gram)), _p(ws), 16, _stream())
     return (Ag if gated else A), gram, B, Bv
 
 
@@ -401,6 +401,27 @@ def pair_rows(z: Tensor, src_p: Tensor, dst_p: Tensor, zdim: int) -> Tensor:
     row = torch.empty(E, device=z.device, dtype=torch.int32)
     _call("lcao_pair_rows", _p(z), _p(_i32(src_p)), _p(_i32(dst_p)), E, zdim, _p(row), _stream())
     return row
+
+
+_TILE_WS: dict = {}
+_TILE_WS_CAPTURED: list = []
+
+
+def tile_queue_workspace(dev) -> Tensor:
+    """The 16-byte tile queue of the persistent coefficient kernels (include/lcaonet_hip.h): zero on first use, left zero
+    by every launch.  One per (device, stream), kept for the life of the process — launches on one stream are ordered, and
+    an address that is never freed can be baked into a captured HIP graph.  While a graph is being captured a fresh
+    workspace is taken from the capture's pool and kept alive, so replays of different captures never share one."""
+    dev = torch.device(dev)
+    if torch.cuda.is_current_stream_capturing():
+        ws = torch.zeros(4, device=dev, dtype=torch.int32)
+        _TILE_WS_CAPTURED.append(ws)
+        return ws
+    key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _TILE_WS.get(key)
+    if ws is None:
+        ws = _TILE_WS[key] = torch.zeros(4, device=dev, dtype=torch.int32)
+    return ws
 
 
 def coeff_mlp_buffers(E, V, n_l, dev, gated: bool, valence: bool):

@@ -874,6 +874,38 @@ def test_captured_forward_replays_with_new_positions(dev, forces):
             assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_captured_forward_with_dynamic_tiles_interleaved_with_eager(dev, precision):
+    """Replays of a captured forward at a size where the coefficient kernel DRAWS tiles from its device-side queue
+    (more 16-edge tiles than resident waves), interleaved with eager forwards and with fresh allocator segments, stay
+    bitwise equal to the eager result.  Regression test: while the queue was re-armed by a hipMemsetAsync on a
+    per-call workspace, such replays lost the drawn tiles after some iterations or faulted
+    (profiles/r02/graph_replay_tile_queue.txt); the queue now re-arms itself on a workspace that is never freed."""
+    from lcaonet_amd import ops
+    from lcaonet_amd.data.synthetic import jittered_cubic_cells
+    from lcaonet_amd.model import CapturedForward
+    kw = dict(emb_size=64, emb_size_coeff=64, emb_size_conv=64, n_interaction=3, cutoff=5.0)
+    m, _ = _random_model(dev, 11, **kw)
+    g = jittered_cubic_cells(80, n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, seed=3, device=dev)
+    E = g["edge_index"].shape[1]
+    waves = 2 * 8 * torch.cuda.get_device_properties(dev).multi_processor_count     # <= 2 workgroups of 8 waves per CU
+    assert E // 16 > waves, "the batch must be larger than the statically assigned tiles"
+    mkw = {} if precision == "fp32" else {"precision": precision}
+    with torch.no_grad():
+        ref = m(g, **mkw).clone()
+        step = CapturedForward(m, g, **mkw)
+        keep = []
+        for i in range(40):
+            a = m(g, **mkw)
+            b = step(g["pos"])
+            assert torch.equal(a, ref), f"eager forward changed at iteration {i}"
+            assert torch.equal(b, ref), f"replay differs at iteration {i}"
+            if i % 8 == 0:
+                keep.append(torch.zeros((i + 1) * 2**22, dtype=torch.uint8, device=dev))   # new allocator segments
+    ws = ops.tile_queue_workspace(dev)
+    assert int(ws.abs().sum()) == 0, "every launch must leave the tile queue re-armed"
+
+
 def test_md_energy_conservation_with_captured_forces(dev):
     """A size-independent property of the force path: velocity-Verlet dynamics driven by the replayed HIP graph
     (CapturedForward, fixed edge list with a skin) conserves kinetic + potential energy while the potential energy itself

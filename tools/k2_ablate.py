@@ -17,7 +17,7 @@ src = torch.sort(torch.randint(0, N, (E,), device=dev, generator=g)).values.to(t
 order = torch.arange(E, device=dev, dtype=torch.int32)
 l_of_d = torch.tensor([0, 0, 1, 0, 1, 0, 2, 1], dtype=torch.int32, device=dev)
 B = torch.empty(E, V, device=dev); Ag = torch.empty(E, NL, V, device=dev); gram = torch.empty(E, 10, device=dev)
-ws = torch.zeros(2, dtype=torch.int32, device=dev)
+ws = torch.zeros(4, dtype=torch.int32, device=dev)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 for path in sorted(glob.glob(sys.argv[1] + "/lib*.so")):
     lib = ctypes.CDLL(path)
@@ -25,7 +25,7 @@ for path in sorted(glob.glob(sys.argv[1] + "/lib*.so")):
     fn.argtypes = _lib.SIGNATURES["lcao_coeff_mlp_contract"]
     def run():
         rc = fn(p(cst), p(rb), p(order), None, p(l_of_d), None, p(W1), p(W2), p(gate), p(src), E, D, C, V, NL, 0, None, p(B), None,
-                p(Ag), p(gram), p(ws), 8, None)
+                p(Ag), p(gram), p(ws), 16, None)
         assert rc == 0, rc
     for _ in range(3):
         run()
