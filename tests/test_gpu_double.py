@@ -314,6 +314,32 @@ def test_rowgram_family_first_and_second_derivatives(dev):
         ops.rowmix(torch.zeros(3, 2, 2, device=dev), torch.zeros(3, 4, 32, device=dev))
 
 
+def test_force_training_gradients_are_additive_over_graphs(dev):
+    """A size-independent property at a size the oracle cannot hold (96 crystals, ~108 k edges, ~1.9 M triplets — past the
+    single-tile / single-chunk regime of every kernel of the twice-differentiable path): in eval mode the graphs of a
+    batch are independent, so d/dtheta sum_g (E_g^2 + |F_g|^2) over the whole batch equals the sum over its two halves."""
+    from lcaonet_amd.data.synthetic import jittered_cubic_cells
+    kw = dict(emb_size=64, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=5.0, regress_forces=True,
+              direct_forces=False)
+    m, _ = _random_model(dev, 5, grad=True, **kw)
+    gk = dict(n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, device=dev)
+    whole = jittered_cubic_cells(96, seed=21, cell_range=(0, 96), **gk)
+    halves = [jittered_cubic_cells(96, seed=21, cell_range=r, **gk) for r in ((0, 48), (48, 96))]
+
+    def grads(g):
+        m.zero_grad(set_to_none=True)
+        e, f = m(g)
+        ((e * e).sum() + (f * f).sum()).backward()
+        return [p.grad.clone() for p in m.parameters() if p.grad is not None], e.detach(), f.detach()
+    gw, ew, fw = grads(whole)
+    parts = [grads(h) for h in halves]
+    assert torch.equal(ew, torch.cat([p[1] for p in parts])) or relerr(ew, torch.cat([p[1] for p in parts])) <= 1e-6
+    assert relerr(fw, torch.cat([p[2] for p in parts])) <= 1e-6
+    assert float(fw.abs().max()) > 0
+    worst = max(relerr(a, b + c) for a, b, c in zip(gw, parts[0][0], parts[1][0]))
+    assert worst <= 2e-5, worst
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # single-graph TRAINING over ranks (BatchNorm statistics of the whole graph, autograd-aware halo exchange)
 # ---------------------------------------------------------------------------------------------------------------------
