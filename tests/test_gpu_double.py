@@ -314,6 +314,37 @@ def test_rowgram_family_first_and_second_derivatives(dev):
         ops.rowmix(torch.zeros(3, 2, 2, device=dev), torch.zeros(3, 4, 32, device=dev))
 
 
+@pytest.mark.parametrize("mode", ["inference-forces", "energy-gradients"])
+def test_reverse_sweeps_are_additive_over_graphs_at_mid_size(dev, mode):
+    """The same property for the hand-written reverse sweeps (model/forces.py, model/train.py) at ~108 k edges: forces of the
+    whole batch equal the forces of its halves, and eval-mode parameter gradients of sum_g E_g^2 add up."""
+    from lcaonet_amd.data.synthetic import jittered_cubic_cells
+    forces = mode == "inference-forces"
+    kw = dict(emb_size=64, emb_size_coeff=64, emb_size_conv=64, n_interaction=2, cutoff=5.0)
+    if forces:
+        kw.update(regress_forces=True, direct_forces=False)
+    m, _ = _random_model(dev, 6, grad=not forces, **kw)
+    gk = dict(n_side=4, a=3.2, sigma=0.05, cutoff_graph=4.95, device=dev)
+    whole = jittered_cubic_cells(96, seed=22, cell_range=(0, 96), **gk)
+    halves = [jittered_cubic_cells(96, seed=22, cell_range=r, **gk) for r in ((0, 48), (48, 96))]
+    if forces:
+        with torch.no_grad():
+            ew, fw = m(whole)
+            parts = [m(h) for h in halves]
+        assert relerr(ew, torch.cat([p[0] for p in parts])) <= 1e-6
+        assert relerr(fw, torch.cat([p[1] for p in parts])) <= 1e-6 and float(fw.abs().max()) > 0
+        return
+
+    def grads(g):
+        m.zero_grad(set_to_none=True)
+        e = m(g)
+        (e * e).sum().backward()
+        return [p.grad.clone() for p in m.parameters() if p.grad is not None]
+    gw, ga, gb = grads(whole), grads(halves[0]), grads(halves[1])
+    worst = max(relerr(a, b + c) for a, b, c in zip(gw, ga, gb))
+    assert worst <= 2e-5, worst
+
+
 def test_force_training_gradients_are_additive_over_graphs(dev):
     """A size-independent property at a size the oracle cannot hold (96 crystals, ~108 k edges, ~1.9 M triplets — past the
     single-tile / single-chunk regime of every kernel of the twice-differentiable path): in eval mode the graphs of a
