@@ -648,9 +648,11 @@ template <int V>
 __global__ __launch_bounds__(256) void k_edge_node_message_agg(
     const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
     const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr,
-    const float* __restrict__ Wn2, const float* __restrict__ bn2, int n_nodes, int chunk_nodes, float* __restrict__ agg) {
+    const float* __restrict__ Wn2, const float* __restrict__ bn2, int n_nodes, int chunk_nodes,
+    const int32_t* __restrict__ hint, float* __restrict__ agg) {
   constexpr int MT = V / 16;
   extern __shared__ float lds[];
+  if (hint && *hint != 0) return;   // even degrees: k_edge_node_message_cols (launched next) writes every row of agg
   stage_weights(lds, Wn2, V, V, V);
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -787,9 +789,131 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
   }
 }
 
+// ===================================================================================================
+// lcao_edge_node_message_agg, "one centre node per MFMA column" form.  A wave takes 16 consecutive centre nodes; in
+// step t its 16 data rows are the t-th out-edge of each of them.  The E -> N sum of lcaonet.py:207-213 is then a
+// per-lane accumulation over t — no cross-lane reduction, no carry, no segment bookkeeping, Ps[s] is loaded once per
+// group, and nodes without edges simply store their zero accumulator (no memset).  The price is padding: a group runs
+// max-degree steps, so the form is used only when the graph's degrees are even enough (lcao_node_column_hint: crystals,
+// fixed-k neighbour lists; molecules of mixed size keep the edge-tiled kernel above).  The fp32 MFMA stream and VALU
+// work do not overlap on this SIMD (profiles/r02/mfma_valu_overlap.txt): this form issues ~330 VALU instructions per
+// 256 MFMAs where the edge-tiled one issues ~970.
+// ===================================================================================================
+__device__ __forceinline__ f32x4v lcao_silu4(f32x4v x) {
+  f32x4v e;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) e[j] = __expf(-x[j]);
+  e = e + 1.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
+  return x * e;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_edge_node_message_cols(
+    const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
+    const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr, const float* __restrict__ Wn2,
+    const float* __restrict__ bn2, int n_nodes, int n_edges, const int32_t* __restrict__ hint, float* __restrict__ agg) {
+  constexpr int MT = V / 16;
+  extern __shared__ float lds[];
+  if (hint && *hint == 0) return;   // uneven degrees: the edge-tiled kernel has produced agg
+  stage_weights(lds, Wn2, V, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int n_groups = (n_nodes + 15) >> 4;
+  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
+    const bool node_ok = 16 * g + r < n_nodes;
+    const int s = node_ok ? 16 * g + r : n_nodes - 1;
+    const int b = out_ptr[s];
+    const int deg = node_ok ? out_ptr[s + 1] - b : 0;
+    int T = deg;   // max over the 16 columns (the four quarters hold the same 16 values)
+    T = max(T, __shfl_xor(T, 1)); T = max(T, __shfl_xor(T, 2)); T = max(T, __shfl_xor(T, 4)); T = max(T, __shfl_xor(T, 8));
+    T = __builtin_amdgcn_readfirstlane(T);
+    f32x4v acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    if (T > 0) {
+      // edge of step t for this column, clamped into the node's own list (or to any valid edge for an edgeless column)
+      auto edge_at = [&](int t) { return deg > 0 ? b + min(t, deg - 1) : min(b, n_edges - 1); };
+      f32x4v ps[MT], h[MT];
+      {
+        const float* pr = Ps + (int64_t)s * V + 4 * q;
+        const float* pt = Pt + (int64_t)dst_p[edge_at(0)] * V + 4 * q;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) ps[a] = *(const f32x4v*)(pr + 16 * a);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) h[a] = lcao_silu4(ps[a] + *(const f32x4v*)(pt + 16 * a));
+      }
+      int d_nxt = dst_p[edge_at(1)];
+      for (int t = 0; t < T; ++t) {
+        asm volatile("" ::: "memory");
+        const int64_t pw = edge_at(t);
+        const float live = t < deg ? 1.0f : 0.0f;
+        // the target rows of step t + 1: requested now, consumed after this step's GEMM (re-read of the last row at the end)
+        f32x4v nt[MT], wv[MT], o[MT];
+        {
+          const float* pt = Pt + (int64_t)d_nxt * V + 4 * q;
+#pragma unroll
+          for (int a = 0; a < MT; ++a) nt[a] = *(const f32x4v*)(pt + 16 * a);
+        }
+        d_nxt = dst_p[edge_at(t + 2)];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wv[m] = *(const f32x4v*)(bw + pw * V + 16 * m + 4 * q);   // in flight under the GEMM
+#pragma unroll
+        for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);   // bias as the initial accumulator
+        __builtin_amdgcn_s_setprio(1);
+        mfma_layer<MT, MT>(lds, V + 4, r, q, h, o);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] += (wv[m] * live) * lcao_silu4(o[m]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) h[a] = lcao_silu4(ps[a] + nt[a]);
+      }
+    }
+    if (node_ok) {
+      float* out = agg + (int64_t)s * V + 4 * q;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *(f32x4v*)(out + 16 * m) = acc[m];
+    }
+  }
+}
+
+// hint[0] = 1 when running every group of 16 consecutive centre nodes for its maximum degree costs at most 10 % more
+// 16-edge steps than the edge list itself has (one workgroup; a few microseconds; built once per edge list)
+__global__ __launch_bounds__(1024) void k_node_column_hint(const int32_t* __restrict__ out_ptr, int n_nodes, int n_edges,
+                                                          int32_t* __restrict__ hint) {
+  __shared__ long long part[1024];
+  long long steps = 0;
+  const int n_groups = (n_nodes + 15) >> 4;
+  for (int g = threadIdx.x; g < n_groups; g += 1024) {
+    int mx = 0;
+    for (int i = 16 * g; i < min(16 * g + 16, n_nodes); ++i) mx = max(mx, out_ptr[i + 1] - out_ptr[i]);
+    steps += mx;
+  }
+  part[threadIdx.x] = steps;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) hint[0] = (part[0] * 160 <= (long long)n_edges * 11 + 160) ? 1 : 0;
+}
+
+extern "C" int lcao_node_column_hint(const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int32_t* hint, void* stream) {
+  LCAO_CHECK_SIZE(n_nodes);
+  LCAO_CHECK_SIZE(n_edges);
+  LCAO_CHECK_PTR(hint);
+  if (n_nodes > 0) LCAO_CHECK_PTR(out_ptr);
+  hipLaunchKernelGGL(k_node_column_hint, dim3(1), dim3(1024), 0, (hipStream_t)stream, out_ptr, (int)n_nodes, (int)n_edges, hint);
+  return lcao_launch_status();
+}
+
 extern "C" int lcao_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
                                           const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
-                                          int64_t n_nodes, int64_t n_edges, int V, float* agg, void* stream) {
+                                          int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* agg,
+                                          void* stream) {
   LCAO_CHECK_SIZE(n_nodes);
   LCAO_CHECK_SIZE(n_edges);
   if (V <= 0) return LCAO_ERR_INVALID;
@@ -810,13 +934,22 @@ extern "C" int lcao_edge_node_message_agg(const float* bw, const float* Ps, cons
   int64_t per_cu = (lds > 80 * 1024) ? 1 : ((lds > 53 * 1024) ? 2 : 3);
   int64_t groups = (n_chunks + 3) / 4, cap = (int64_t)lcao_num_cu() * per_cu;
   if (groups > cap) groups = cap;
+  int64_t cgroups = (((n_nodes + 15) >> 4) + 3) / 4;   // column form: one wave per 16 centre nodes
+  if (cgroups > cap) cgroups = cap;
 #define NMA_CASE(V_)                                                                                             \
   if (V == V_) {                                                                                                 \
     static bool done = false;                                                                                    \
     int rc = set_lds_attr(k_edge_node_message_agg<V_>, lds, done);                                               \
     if (rc != LCAO_OK) return rc;                                                                                \
     hipLaunchKernelGGL(k_edge_node_message_agg<V_>, dim3((unsigned)groups), dim3(256), lds, st, bw, Ps, Pt, src_p,   \
-                       dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)chunk_nodes, agg);                           \
+                       dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)chunk_nodes, column_hint, agg);              \
+    if (column_hint) {                                                                                           \
+      static bool done2 = false;                                                                                 \
+      rc = set_lds_attr(k_edge_node_message_cols<V_>, lds, done2);                                               \
+      if (rc != LCAO_OK) return rc;                                                                              \
+      hipLaunchKernelGGL(k_edge_node_message_cols<V_>, dim3((unsigned)cgroups), dim3(256), lds, st, bw, Ps, Pt,  \
+                         dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)n_edges, column_hint, agg);                \
+    }                                                                                                            \
     return lcao_launch_status();                                                                                 \
   }
   NMA_CASE(128) NMA_CASE(64) NMA_CASE(32)

@@ -59,6 +59,17 @@ class EdgeContext:
     dst_o: Tensor      # (E)   idx_t as int32, orig order
     _uvec_p: Tensor | None = None
     _uvec_src: Tensor | None = None
+    _col_hints: dict | None = None
+
+    def column_hint(self, out_ptr: Tensor, n_edges: int) -> Tensor:
+        """Device-side flag for ops.edge_node_message_agg (per-node-column form when the degrees are even); depends on the
+        edge list only: one tiny launch per (context, number of centres), no host synchronisation."""
+        if self._col_hints is None:
+            self._col_hints = {}
+        key = (out_ptr.numel(), n_edges)
+        if key not in self._col_hints:
+            self._col_hints[key] = ops.node_column_hint(out_ptr, n_edges)
+        return self._col_hints[key]
 
     def uvec_p(self, uvec: Tensor) -> Tensor:
         """Unit vectors permuted to p-space (computed once per forward and shared by the layers; a context that
@@ -365,7 +376,7 @@ class LCAOInteraction(nn.Module):
             bw = ops.edge_lcao_weight(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach(), precision)
             if precision == "fp32":   # message rows summed per centre inside the kernel: msg (E, V) never exists
                 agg = ops.edge_node_message_agg(bw, Ps, Pt, src_own, dst_own, out_ptr, self.f_node[2].weight.detach(),
-                                                self.f_node[2].bias.detach())
+                                                self.f_node[2].bias.detach(), ctx.column_hint(out_ptr, e_own))
             else:
                 msg = ops.edge_node_message(bw, Ps, Pt, src_own, dst_own, self.f_node[2].weight.detach(),
                                             self.f_node[2].bias.detach(), precision)

@@ -544,15 +544,24 @@ def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, precision="fp32", save
     return msg
 
 
-def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2):
+def node_column_hint(out_ptr, n_edges: int) -> Tensor:
+    """(1,) int32 on the device: 1 if the per-node-column form of edge_node_message_agg pays for this edge list."""
+    out_ptr = _i32(out_ptr)
+    hint = torch.zeros(1, device=out_ptr.device, dtype=torch.int32)
+    _call("lcao_node_column_hint", _p(out_ptr), out_ptr.numel() - 1, n_edges, _p(hint), _stream())
+    return hint
+
+
+def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hint=None):
     """agg (n_centres, V): edge_node_message + the per-centre segment sum in one kernel (msg is never materialised).
-    out_ptr (n_centres + 1) int32; the first out_ptr[-1] rows of bw / src_p / dst_p are the centres' out-edges."""
+    out_ptr (n_centres + 1) int32; the first out_ptr[-1] rows of bw / src_p / dst_p are the centres' out-edges.
+    column_hint: node_column_hint(out_ptr, E) of this edge list (device-side choice of the per-node-column form)."""
     bw, Ps, Pt, Wn2, bn2 = _f32(bw), _f32(Ps), _f32(Pt), _f32(Wn2), _f32(bn2)
     E, V = bw.shape
     n = out_ptr.numel() - 1
     agg = torch.empty(n, V, device=bw.device, dtype=torch.float32)
     _call("lcao_edge_node_message_agg", _p(bw), _p(Ps), _p(Pt), _p(_i32(src_p)), _p(_i32(dst_p)), _p(_i32(out_ptr)), _p(Wn2),
-          _p(bn2), n, E, V, _p(agg), _stream())
+          _p(bn2), n, E, V, _p(column_hint) if column_hint is not None else None, _p(agg), _stream())
     return agg
 
 

@@ -874,6 +874,41 @@ def test_captured_forward_replays_with_new_positions(dev, forces):
             assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("V", [32, 64, 128])
+def test_edge_node_message_agg_both_forms_vs_fp64(dev, V):
+    """lcao_edge_node_message_agg (lcaonet.py:207-213: f_node.2, message product, E -> N sum) in its two forms — 16-edge tiles
+    with segmented lane sums, and one centre node per MFMA column — against the same sum from fp64 tensor ops, on a graph
+    with uneven degrees, edgeless nodes (first, inside, last) and a node count that is no multiple of 16; and the device-side
+    hint that chooses between them."""
+    from lcaonet_amd import ops
+    gen = torch.Generator().manual_seed(V)
+    N = 203
+    deg = torch.randint(0, 41, (N,), generator=gen)
+    deg[0] = 0; deg[57] = 0; deg[58] = 0; deg[N - 1] = 0; deg[100] = 97
+    out_ptr = torch.zeros(N + 1, dtype=torch.int32)
+    out_ptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+    E = int(out_ptr[-1])
+    src = torch.repeat_interleave(torch.arange(N), deg).to(torch.int32)
+    dst = torch.randint(0, N, (E,), generator=gen).to(torch.int32)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen)
+    bw, Ps, Pt, W, b = rnd(E, V), rnd(N, V), rnd(N, V), rnd(V, V) / V**0.5, rnd(V)
+    h1 = torch.nn.functional.silu(Ps.double()[src.long()] + Pt.double()[dst.long()])
+    msg = bw.double() * torch.nn.functional.silu(h1 @ W.double().t() + b.double())
+    want = torch.zeros(N, V, dtype=torch.float64).index_add_(0, src.long(), msg)
+    args = [t.to(dev) for t in (bw, Ps, Pt, src, dst, out_ptr, W, b)]
+    got = {}
+    for form in (0, 1):
+        hint = torch.full((1,), form, dtype=torch.int32, device=dev)
+        got[form] = ops.edge_node_message_agg(*args, column_hint=hint)
+        assert relerr(got[form], want) <= 2e-6, (form, relerr(got[form], want))
+        assert bool((got[form][[0, 57, 58, N - 1]] == 0).all()), "edgeless nodes must read zero"
+    assert relerr(ops.edge_node_message_agg(*args), want) <= 2e-6            # no hint: the edge-tiled form
+    assert int(ops.node_column_hint(args[5], E)) == 0                            # degrees 0..97: padding would double the work
+    even = torch.arange(0, 18 * 64 + 1, 18, dtype=torch.int32, device=dev)       # 64 nodes x 18 edges
+    assert int(ops.node_column_hint(even, 18 * 64)) == 1
+    assert int(ops.node_column_hint(torch.zeros(1, dtype=torch.int32, device=dev), 0)) in (0, 1)   # empty graph: any
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f16"])
 def test_captured_forward_with_dynamic_tiles_interleaved_with_eager(dev, precision):
     """Replays of a captured forward at a size where the coefficient kernel DRAWS tiles from its device-side queue

@@ -23,7 +23,8 @@ for path in sorted(glob.glob(sys.argv[1] + "/lib*.so")):
     lib = ctypes.CDLL(path)
     fn = lib.lcao_edge_node_message_agg
     fn.argtypes = _lib.SIGNATURES["lcao_edge_node_message_agg"]
-    run = lambda: fn(p(bw), p(Ps), p(Pt), p(ctx.src_p), p(ctx.dst_p), p(ctx.out_ptr), p(Wn2), p(bn2), N, E, V, p(agg), None)
+    hint = torch.full((1,), int(os.environ.get("K4B_COLS", "0")), dtype=torch.int32, device=dev)   # 1: per-node-column form
+    run = lambda: fn(p(bw), p(Ps), p(Pt), p(ctx.src_p), p(ctx.dst_p), p(ctx.out_ptr), p(Wn2), p(bn2), N, E, V, p(hint), p(agg), None)
     for _ in range(3): assert run() == 0
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
