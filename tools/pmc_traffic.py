@@ -24,6 +24,9 @@ out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
        "_correction": "bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (MI355X_MICROARCH.md, HBM: FETCH_SIZE counts 1/2 of wide "
                       "coalesced 16-B/lane reads on gfx950; cache-resident table reads never reach these memory-side counters)",
        "_commit": sys.argv[4], "_date": sys.argv[5]}
+# entries served by two kernels per call of which one returns at once (device-side choice): per-call traffic = the SUM of the
+# two kernels' per-launch means
+PAIRED = {"lcao_edge_node_message_agg": "k_edge_node_message_cols<"}
 for entry, pat in ENTRY.items():
     f = [(k, v) for k, v in fetch.items() if pat in k]
     w = [(k, v) for k, v in write.items() if pat in k]
@@ -31,6 +34,12 @@ for entry, pat in ENTRY.items():
         continue
     fk = sum(v[0] * v[1] for _, v in f) / sum(v[1] for _, v in f)
     wk = sum(v[0] * v[1] for _, v in w) / sum(v[1] for _, v in w)
+    if entry in PAIRED:
+        f2 = [v for k, v in fetch.items() if PAIRED[entry] in k]
+        w2 = [v for k, v in write.items() if PAIRED[entry] in k]
+        if f2 and w2:
+            fk += sum(v[0] * v[1] for v in f2) / sum(v[1] for v in f2)
+            wk += sum(v[0] * v[1] for v in w2) / sum(v[1] for v in w2)
     out[entry] = {"fetch_kib": round(fk, 1), "write_kib": round(wk, 1), "launches_seen": int(sum(v[1] for _, v in f)),
                   "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
