@@ -385,7 +385,9 @@ def main():
                 kall = prof_all.summary()
         except Exception as e:  # noqa: BLE001
             secondary_error = f"{type(e).__name__}: {e}"
-    if rank == 0 and not args.no_secondary and args.precision == "fp32":
+    # secondary modes are one-GPU measurements: reported by the N = 1 run only (at N > 1 the other ranks would sit in the final
+    # barrier while rank 0 runs them)
+    if rank == 0 and world == 1 and not args.no_secondary and args.precision == "fp32":
         try:
             if not with_forces:   # the force workloads already run on the pair table; no secondary modes there
                 mat_ms, mat_err = timed(cst_mode="edge_tensor")              # cst materialised per edge as the reference holds it
