@@ -237,6 +237,18 @@ int lcao_edge_node_message_bf16x3(const float* bw, const float* Ps, const float*
                                   const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
                                   float* msg, void* stream);
 
+/* lcao_edge_node_message_agg in the two 16-bit precisions: with column_hint reading 1 the per-node-column kernel; otherwise
+ * (or with column_hint == NULL) the message rows go through `msg` (E, V scratch) and a per-node sum.  Same device-side
+ * choice as the fp32 form; agg (n_nodes, V) is fully written either way. */
+int lcao_edge_node_message_agg_bf16x3(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                      const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                                      int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* msg,
+                                      float* agg, void* stream);
+int lcao_edge_node_message_agg_f16(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                   const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                                   int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* msg,
+                                   float* agg, void* stream);
+
 /* Species-pair form of lcaonet.py:170-183,200 (eval mode, no valence): with
  * Tf[(z_s*zdim + z_t), d, :] = f_coeffs(cst(z_s, z_t))[d, :] precomputed on the (zdim^2, D, V) pair table,
  *   A[p,l,:] = sum_{d in l} rb[e,d] * Tf[pair(p),d,:];  writes Ag = A * gate[src_p], B = sum_l A, gram = A A^T

@@ -381,10 +381,12 @@ template <int PREC, int V>
 __global__ __launch_bounds__(256) void k_edge_node_message_lowp(
     const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
     const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, const float* __restrict__ Wn2,
-    const float* __restrict__ bn2, int64_t E, float* __restrict__ msg) {
+    const float* __restrict__ bn2, int64_t E, const int32_t* __restrict__ skip_if /* nullable: return when it reads 1 */,
+    float* __restrict__ msg) {
   typedef typename LowP<PREC>::T T;
   constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
   extern __shared__ unsigned char lds_raw[];
+  if (skip_if && *skip_if != 0) return;
   T* wp = (T*)lds_raw;
   stage_weights_lowp<PREC, false>(wp, Wn2, V, V);
   __syncthreads();
@@ -422,6 +424,118 @@ __global__ __launch_bounds__(256) void k_edge_node_message_lowp(
   }
 }
 
+// "one centre node per MFMA column" form of the message kernel with the E -> N sum fused in (see lcao_mfma.hip,
+// k_edge_node_message_cols): step t multiplies the t-th out-edge of 16 consecutive centre nodes, the node sum is a per-lane
+// accumulation.  Chosen on the device by lcao_node_column_hint; the edge-tiled kernel above + k_rows_segment_sum serve
+// graphs with uneven degrees.
+template <int PREC, int V>
+__global__ __launch_bounds__(256) void k_edge_node_message_cols_lowp(
+    const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
+    const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr, const float* __restrict__ Wn2,
+    const float* __restrict__ bn2, int n_nodes, int n_edges, const int32_t* __restrict__ hint, float* __restrict__ agg) {
+  typedef typename LowP<PREC>::T T;
+  constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
+  extern __shared__ unsigned char lds_raw[];
+  if (hint && *hint == 0) return;
+  T* wp = (T*)lds_raw;
+  stage_weights_lowp<PREC, false>(wp, Wn2, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int n_groups = (n_nodes + 15) >> 4;
+  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
+    const bool node_ok = 16 * g + r < n_nodes;
+    const int s = node_ok ? 16 * g + r : n_nodes - 1;
+    const int b = out_ptr[s];
+    const int deg = node_ok ? out_ptr[s + 1] - b : 0;
+    int Tn = deg;
+    Tn = max(Tn, __shfl_xor(Tn, 1)); Tn = max(Tn, __shfl_xor(Tn, 2)); Tn = max(Tn, __shfl_xor(Tn, 4)); Tn = max(Tn, __shfl_xor(Tn, 8));
+    Tn = __builtin_amdgcn_readfirstlane(Tn);
+    f32x4v acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    if (Tn > 0) {
+      auto edge_at = [&](int t) { return deg > 0 ? b + min(t, deg - 1) : min(b, n_edges - 1); };
+      // PF: the target rows of step t + 1 are requested before step t's GEMM (fp16: registers allow it); bf16x3 (three MFMAs
+      // and two operand splits per product) has no room for that at two waves per SIMD and reads them at the top of the step
+      constexpr bool PF = PREC != PREC_BF16X3;
+      float hin[KS][8];
+      const float* pr = Ps + (int64_t)s * V + 8 * q;   // the centre's own row: re-read per step (an L1 hit; 32 VGPRs saved)
+      auto first_layer = [&](int d) {
+        const float* pt = Pt + (int64_t)d * V + 8 * q;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const f32x4v a0 = *(const f32x4v*)(pt + 32 * k) + *(const f32x4v*)(pr + 32 * k);
+          const f32x4v a1 = *(const f32x4v*)(pt + 32 * k + 4) + *(const f32x4v*)(pr + 32 * k + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { hin[k][j] = lcao_silu(a0[j]); hin[k][4 + j] = lcao_silu(a1[j]); }
+        }
+      };
+      int d_cur = dst_p[edge_at(0)], d_nxt = dst_p[edge_at(1)];
+      if (PF) first_layer(d_cur);
+      for (int t = 0; t < Tn; ++t) {
+        asm volatile("" ::: "memory");
+        const int64_t pw = edge_at(t);
+        const float live = t < deg ? 1.0f : 0.0f;
+        f32x4v wv[MT], o[MT];
+        if (!PF) first_layer(d_cur);
+        f32x4v ntv[PF ? KS : 1][2];
+        if (PF) {
+          const float* pt = Pt + (int64_t)d_nxt * V + 8 * q;
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            ntv[PF ? k : 0][0] = *(const f32x4v*)(pt + 32 * k) + *(const f32x4v*)(pr + 32 * k);
+            ntv[PF ? k : 0][1] = *(const f32x4v*)(pt + 32 * k + 4) + *(const f32x4v*)(pr + 32 * k + 4);
+          }
+        }
+        d_cur = d_nxt;
+        d_nxt = dst_p[edge_at(t + 2)];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wv[m] = *(const f32x4v*)(bw + pw * V + 16 * m + 4 * q);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
+        lowp_layer<PREC, KS, MT>(wp, V, LD, r, q, hin, o);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[m][j] += (wv[m][j] * live) * lcao_silu(o[m][j]);
+        if (PF) {
+#pragma unroll
+          for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              hin[k][j] = lcao_silu(ntv[PF ? k : 0][0][j]);
+              hin[k][4 + j] = lcao_silu(ntv[PF ? k : 0][1][j]);
+            }
+        }
+      }
+    }
+    if (node_ok) {
+      float* out = agg + (int64_t)s * V + 4 * q;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *(f32x4v*)(out + 16 * m) = acc[m];
+    }
+  }
+}
+
+// out[s, :] = sum of rows[out_ptr[s] : out_ptr[s+1], :]  (one wave per centre node, lanes over channels, fixed order);
+// returns at once when *skip_if reads 1
+__global__ void k_rows_segment_sum(const float* __restrict__ rows, const int32_t* __restrict__ out_ptr, int n_nodes, int V,
+                                   const int32_t* __restrict__ skip_if, float* __restrict__ out) {
+  if (skip_if && *skip_if != 0) return;
+  const int lane = threadIdx.x & 63;
+  const int nwave = (gridDim.x * blockDim.x) >> 6;
+  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_nodes; s += nwave) {
+    const int p0 = out_ptr[s], p1 = out_ptr[s + 1];
+    for (int ch = 4 * lane; ch < V; ch += 256) {
+      f32x4v a = {0.f, 0.f, 0.f, 0.f};
+      for (int p = p0; p < p1; ++p) a += *(const f32x4v*)(rows + (int64_t)p * V + ch);
+      *(f32x4v*)(out + (int64_t)s * V + ch) = a;
+    }
+  }
+}
+
 template <int PREC>
 static int edge_lcao_weight_lowp(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges, int V,
                                  float* bw, void* stream) {
@@ -448,7 +562,7 @@ static int edge_lcao_weight_lowp(const float* tbw, const float* B, const float* 
 template <int PREC>
 static int edge_node_message_lowp(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
                                   const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
-                                  float* msg, void* stream) {
+                                  float* msg, void* stream, const int32_t* column_hint = nullptr) {
   LCAO_CHECK_SIZE(n_edges);
   if (V <= 0) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
@@ -462,7 +576,7 @@ static int edge_node_message_lowp(const float* bw, const float* Ps, const float*
     int rc = set_lds_attr(k_edge_node_message_lowp<PREC, V_>, lds, done);                                            \
     if (rc != LCAO_OK) return rc;                                                                                    \
     hipLaunchKernelGGL((k_edge_node_message_lowp<PREC, V_>), dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, bw, \
-                       Ps, Pt, src_p, dst_p, Wn2, bn2, n_edges, msg);                                                \
+                       Ps, Pt, src_p, dst_p, Wn2, bn2, n_edges, column_hint, msg);                                   \
     return lcao_launch_status();                                                                                     \
   }
   NML_CASE(128) NML_CASE(64) NML_CASE(32)
@@ -487,4 +601,60 @@ extern "C" int lcao_edge_node_message_f16(const float* bw, const float* Ps, cons
                                           const int32_t* dst_p, const float* Wn2, const float* bn2, int64_t n_edges, int V,
                                           float* msg, void* stream) {
   return edge_node_message_lowp<PREC_F16>(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, n_edges, V, msg, stream);
+}
+
+template <int PREC>
+static int edge_node_message_agg_lowp(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                      const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                                      int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* msg,
+                                      float* agg, void* stream) {
+  LCAO_CHECK_SIZE(n_nodes);
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0 || V % 4) return LCAO_ERR_INVALID;
+  if (n_nodes == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(agg); LCAO_CHECK_PTR(out_ptr);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_edges == 0) {
+    hipError_t me = hipMemsetAsync(agg, 0, sizeof(float) * (size_t)n_nodes * V, st);
+    return me == hipSuccess ? LCAO_OK : int(me);
+  }
+  LCAO_CHECK_PTR(msg);
+  // uneven degrees: message rows, then the per-node sum (both return at once when the hint reads 1)
+  int rc = edge_node_message_lowp<PREC>(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, n_edges, V, msg, stream, column_hint);
+  if (rc != LCAO_OK) return rc;
+  hipLaunchKernelGGL(k_rows_segment_sum, dim3(lcao_blocks(n_nodes, 4, 65536)), dim3(256), 0, st, msg, out_ptr, (int)n_nodes, V,
+                     column_hint, agg);
+  if (!column_hint) return lcao_launch_status();
+  size_t lds = size_t(LowP<PREC>::PLANES) * V * (V + 8) * 2;
+  int64_t per_cu = (lds > 80 * 1024) ? 1 : ((lds > 53 * 1024) ? 2 : 3);
+  int64_t cgroups = (((n_nodes + 15) >> 4) + 3) / 4, cap = (int64_t)lcao_num_cu() * per_cu;
+  if (cgroups > cap) cgroups = cap;
+#define NMC_CASE(V_)                                                                                                  \
+  if (V == V_) {                                                                                                      \
+    static bool done = false;                                                                                         \
+    rc = set_lds_attr(k_edge_node_message_cols_lowp<PREC, V_>, lds, done);                                            \
+    if (rc != LCAO_OK) return rc;                                                                                     \
+    hipLaunchKernelGGL((k_edge_node_message_cols_lowp<PREC, V_>), dim3((unsigned)cgroups), dim3(256), lds, st, bw, Ps, Pt, \
+                       dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)n_edges, column_hint, agg);                       \
+    return lcao_launch_status();                                                                                      \
+  }
+  NMC_CASE(128) NMC_CASE(64) NMC_CASE(32)
+#undef NMC_CASE
+  return LCAO_ERR_UNSUPPORTED;
+}
+
+extern "C" int lcao_edge_node_message_agg_bf16x3(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                                 const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2,
+                                                 const float* bn2, int64_t n_nodes, int64_t n_edges, int V,
+                                                 const int32_t* column_hint, float* msg, float* agg, void* stream) {
+  return edge_node_message_agg_lowp<PREC_BF16X3>(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, n_nodes, n_edges, V,
+                                                 column_hint, msg, agg, stream);
+}
+
+extern "C" int lcao_edge_node_message_agg_f16(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                              const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2,
+                                              const float* bn2, int64_t n_nodes, int64_t n_edges, int V,
+                                              const int32_t* column_hint, float* msg, float* agg, void* stream) {
+  return edge_node_message_agg_lowp<PREC_F16>(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, n_nodes, n_edges, V, column_hint,
+                                              msg, agg, stream);
 }

@@ -374,13 +374,10 @@ class LCAOInteraction(nn.Module):
         # two-body term and messages
         if fused and not self.add_valence:
             bw = ops.edge_lcao_weight(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach(), precision)
-            if precision == "fp32":   # message rows summed per centre inside the kernel: msg (E, V) never exists
-                agg = ops.edge_node_message_agg(bw, Ps, Pt, src_own, dst_own, out_ptr, self.f_node[2].weight.detach(),
-                                                self.f_node[2].bias.detach(), ctx.column_hint(out_ptr, e_own))
-            else:
-                msg = ops.edge_node_message(bw, Ps, Pt, src_own, dst_own, self.f_node[2].weight.detach(),
-                                            self.f_node[2].bias.detach(), precision)
-                agg = ops.segment_sum(msg, out_ptr)
+            # message rows summed per centre inside the kernel (msg (E, V) exists only as the scratch of the 16-bit forms'
+            # fallback for uneven degrees)
+            agg = ops.edge_node_message_agg(bw, Ps, Pt, src_own, dst_own, out_ptr, self.f_node[2].weight.detach(),
+                                            self.f_node[2].bias.detach(), ctx.column_hint(out_ptr, e_own), precision)
         else:
             ft = run_mlp(self.f_three, tbw)
             lw = ops.edge_combine(ft, B, Bv)

@@ -552,14 +552,21 @@ def node_column_hint(out_ptr, n_edges: int) -> Tensor:
     return hint
 
 
-def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hint=None):
+def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hint=None, precision="fp32"):
     """agg (n_centres, V): edge_node_message + the per-centre segment sum in one kernel (msg is never materialised).
     out_ptr (n_centres + 1) int32; the first out_ptr[-1] rows of bw / src_p / dst_p are the centres' out-edges.
-    column_hint: node_column_hint(out_ptr, E) of this edge list (device-side choice of the per-node-column form)."""
+    column_hint: node_column_hint(out_ptr, E) of this edge list (device-side choice of the per-node-column form).
+    precision in LOWP: the 16-bit MFMA forms; their fallback for uneven degrees goes through a message scratch."""
     bw, Ps, Pt, Wn2, bn2 = _f32(bw), _f32(Ps), _f32(Pt), _f32(Wn2), _f32(bn2)
     E, V = bw.shape
     n = out_ptr.numel() - 1
     agg = torch.empty(n, V, device=bw.device, dtype=torch.float32)
+    if precision in LOWP:
+        msg = torch.empty(E, V, device=bw.device, dtype=torch.float32)
+        _call("lcao_edge_node_message_agg_" + precision, _p(bw), _p(Ps), _p(Pt), _p(_i32(src_p)), _p(_i32(dst_p)),
+              _p(_i32(out_ptr)), _p(Wn2), _p(bn2), n, E, V, _p(column_hint) if column_hint is not None else None, _p(msg),
+              _p(agg), _stream())
+        return agg
     _call("lcao_edge_node_message_agg", _p(bw), _p(Ps), _p(Pt), _p(_i32(src_p)), _p(_i32(dst_p)), _p(_i32(out_ptr)), _p(Wn2),
           _p(bn2), n, E, V, _p(column_hint) if column_hint is not None else None, _p(agg), _stream())
     return agg

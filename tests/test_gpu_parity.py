@@ -903,6 +903,17 @@ def test_edge_node_message_agg_both_forms_vs_fp64(dev, V):
         assert relerr(got[form], want) <= 2e-6, (form, relerr(got[form], want))
         assert bool((got[form][[0, 57, 58, N - 1]] == 0).all()), "edgeless nodes must read zero"
     assert relerr(ops.edge_node_message_agg(*args), want) <= 2e-6            # no hint: the edge-tiled form
+    # the 16-bit forms: message rows + per-node sum (hint 0 / none) and the per-node-column kernel (hint 1) agree with each
+    # other to fp32 rounding and with fp64 to the precision of the mode
+    for precision, tol in (("bf16x3", 2e-5), ("f16", 3e-3)):
+        lo = {}
+        for form in (0, 1):
+            hint = torch.full((1,), form, dtype=torch.int32, device=dev)
+            lo[form] = ops.edge_node_message_agg(*args, column_hint=hint, precision=precision)
+            assert relerr(lo[form], want) <= tol, (precision, form, relerr(lo[form], want))
+            assert bool((lo[form][[0, 57, 58, N - 1]] == 0).all())
+        assert relerr(lo[1], lo[0]) <= 2e-6, (precision, relerr(lo[1], lo[0]))
+        assert relerr(ops.edge_node_message_agg(*args, precision=precision), lo[0]) == 0.0
     assert int(ops.node_column_hint(args[5], E)) == 0                            # degrees 0..97: padding would double the work
     even = torch.arange(0, 18 * 64 + 1, 18, dtype=torch.int32, device=dev)       # 64 nodes x 18 edges
     assert int(ops.node_column_hint(even, 18 * 64)) == 1
