@@ -287,6 +287,11 @@ int lcao_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt
                                const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
                                int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* agg,
                                void* stream);
+/* ... also writing pre2 (E, V), the pre-activation of the second f_node layer, for the reverse sweep (autograd forces, training) */
+int lcao_edge_node_message_agg_saving(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                      const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                                      int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* pre2,
+                                      float* agg, void* stream);
 int lcao_node_column_hint(const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int32_t* hint, void* stream);
 
 /* The same two kernels for a forward pass that will be differentiated (autograd forces, training): they also keep

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lcao_edge_lcao_weight": [P, P, P, P, L, I, P, P],
     "lcao_edge_node_message": [P, P, P, P, P, P, P, L, I, P, P],
     "lcao_edge_node_message_agg": [P, P, P, P, P, P, P, P, L, L, I, P, P, P],
+    "lcao_edge_node_message_agg_saving": [P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],
     "lcao_node_column_hint": [P, L, L, P, P],
     "lcao_edge_node_message_agg_bf16x3": [P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],
     "lcao_edge_node_message_agg_f16": [P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],

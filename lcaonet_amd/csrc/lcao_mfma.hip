@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
     const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
     const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr,
     const float* __restrict__ Wn2, const float* __restrict__ bn2, int n_nodes, int chunk_nodes,
-    const int32_t* __restrict__ hint, float* __restrict__ agg) {
+    const int32_t* __restrict__ hint, float* __restrict__ pre2_out /* (E, V) or null */, float* __restrict__ agg) {
   constexpr int MT = V / 16;
   extern __shared__ float lds[];
   if (hint && *hint != 0) return;   // even degrees: k_edge_node_message_cols (launched next) writes every row of agg
@@ -731,6 +731,10 @@ __global__ __launch_bounds__(256) void k_edge_node_message_agg(
     __builtin_amdgcn_s_setprio(1);
     mfma_layer<MT, MT>(lds, V + 4, r, q, h, o);
     __builtin_amdgcn_s_setprio(0);
+    if (pre2_out && valid) {   // the pre-activation of f_node.2, kept for the reverse sweep
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *(f32x4v*)(pre2_out + pw * V + 16 * m + 4 * q) = o[m];
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -813,7 +817,8 @@ template <int V>
 __global__ __launch_bounds__(256) void k_edge_node_message_cols(
     const float* __restrict__ bw, const float* __restrict__ Ps, const float* __restrict__ Pt,
     const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr, const float* __restrict__ Wn2,
-    const float* __restrict__ bn2, int n_nodes, int n_edges, const int32_t* __restrict__ hint, float* __restrict__ agg) {
+    const float* __restrict__ bn2, int n_nodes, int n_edges, const int32_t* __restrict__ hint,
+    float* __restrict__ pre2_out /* (E, V) or null */, float* __restrict__ agg) {
   constexpr int MT = V / 16;
   extern __shared__ float lds[];
   if (hint && *hint == 0) return;   // uneven degrees: the edge-tiled kernel has produced agg
@@ -866,6 +871,10 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols(
         __builtin_amdgcn_s_setprio(1);
         mfma_layer<MT, MT>(lds, V + 4, r, q, h, o);
         __builtin_amdgcn_s_setprio(0);
+        if (pre2_out && t < deg) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) *(f32x4v*)(pre2_out + pw * V + 16 * m + 4 * q) = o[m];
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] += (wv[m] * live) * lcao_silu4(o[m]);
 #pragma unroll
@@ -910,10 +919,10 @@ extern "C" int lcao_node_column_hint(const int32_t* out_ptr, int64_t n_nodes, in
   return lcao_launch_status();
 }
 
-extern "C" int lcao_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
-                                          const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
-                                          int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* agg,
-                                          void* stream) {
+static int launch_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                        const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                                        int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* pre2,
+                                        float* agg, void* stream) {
   LCAO_CHECK_SIZE(n_nodes);
   LCAO_CHECK_SIZE(n_edges);
   if (V <= 0) return LCAO_ERR_INVALID;
@@ -942,19 +951,36 @@ extern "C" int lcao_edge_node_message_agg(const float* bw, const float* Ps, cons
     int rc = set_lds_attr(k_edge_node_message_agg<V_>, lds, done);                                               \
     if (rc != LCAO_OK) return rc;                                                                                \
     hipLaunchKernelGGL(k_edge_node_message_agg<V_>, dim3((unsigned)groups), dim3(256), lds, st, bw, Ps, Pt, src_p,   \
-                       dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)chunk_nodes, column_hint, agg);              \
+                       dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)chunk_nodes, column_hint, pre2, agg);        \
     if (column_hint) {                                                                                           \
       static bool done2 = false;                                                                                 \
       rc = set_lds_attr(k_edge_node_message_cols<V_>, lds, done2);                                               \
       if (rc != LCAO_OK) return rc;                                                                              \
       hipLaunchKernelGGL(k_edge_node_message_cols<V_>, dim3((unsigned)cgroups), dim3(256), lds, st, bw, Ps, Pt,  \
-                         dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)n_edges, column_hint, agg);                \
+                         dst_p, out_ptr, Wn2, bn2, (int)n_nodes, (int)n_edges, column_hint, pre2, agg);          \
     }                                                                                                            \
     return lcao_launch_status();                                                                                 \
   }
   NMA_CASE(128) NMA_CASE(64) NMA_CASE(32)
 #undef NMA_CASE
   return LCAO_ERR_UNSUPPORTED;
+}
+
+extern "C" int lcao_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                          const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
+                                          int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* agg,
+                                          void* stream) {
+  return launch_edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, n_nodes, n_edges, V, column_hint, nullptr,
+                                      agg, stream);
+}
+
+extern "C" int lcao_edge_node_message_agg_saving(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
+                                                 const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2,
+                                                 const float* bn2, int64_t n_nodes, int64_t n_edges, int V,
+                                                 const int32_t* column_hint, float* pre2, float* agg, void* stream) {
+  if (n_edges > 0) LCAO_CHECK_PTR(pre2);
+  return launch_edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, n_nodes, n_edges, V, column_hint, pre2,
+                                      agg, stream);
 }
 
 static int launch_edge_lcao_weight(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges,

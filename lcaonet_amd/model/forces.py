@@ -68,9 +68,8 @@ def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim,
         # the forward's fused two-body kernels, keeping ft and pre2; pre1 = Ps[s] + Pt[t] is recomputed in the sweep
         bw, ft = ops.edge_lcao_weight(tbw, B, layer.f_three[0].weight.detach(), layer.basis_weight.weight.detach(),
                                       save=True)
-        msg, pre2 = ops.edge_node_message(bw, Ps, Pt, src_own, dst_own, layer.f_node[2].weight.detach(),
-                                          layer.f_node[2].bias.detach(), save=True)
-        agg = ops.segment_sum(msg, out_ptr)
+        agg, pre2 = ops.edge_node_message_agg(bw, Ps, Pt, src_own, dst_own, out_ptr, layer.f_node[2].weight.detach(),
+                                              layer.f_node[2].bias.detach(), ctx.column_hint(out_ptr, e_own), save=True)
         pre1 = None
     else:
         ft = ops.dense(tbw, layer.f_three[0].weight.detach())

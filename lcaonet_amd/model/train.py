@@ -182,8 +182,8 @@ class LCAOStackFn(torch.autograd.Function):
             tbw = ops.triplet_gemm(Ag, gram, geom.uvec_p, ctx.in_ptr, ctx.in_pos, ctx.out_ptr)
             if V in ops.FUSED_WIDTHS and not valence:
                 bw, ft = ops.edge_lcao_weight(tbw, B, W3, Wb, save=True)
-                msg, pre2 = ops.edge_node_message(bw, Ps, Pt, ctx.src_p, ctx.dst_p, Wn2, bn2, save=True)
-                agg = ops.segment_sum(msg, ctx.out_ptr)
+                agg, pre2 = ops.edge_node_message_agg(bw, Ps, Pt, ctx.src_p, ctx.dst_p, ctx.out_ptr, Wn2, bn2,
+                                                      ctx.column_hint(ctx.out_ptr, ctx.n_edges), save=True)
                 pre1 = None
             else:
                 ft = ops.dense(tbw, W3)

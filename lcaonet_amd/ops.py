@@ -552,7 +552,7 @@ def node_column_hint(out_ptr, n_edges: int) -> Tensor:
     return hint
 
 
-def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hint=None, precision="fp32"):
+def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hint=None, precision="fp32", save=False):
     """agg (n_centres, V): edge_node_message + the per-centre segment sum in one kernel (msg is never materialised).
     out_ptr (n_centres + 1) int32; the first out_ptr[-1] rows of bw / src_p / dst_p are the centres' out-edges.
     column_hint: node_column_hint(out_ptr, E) of this edge list (device-side choice of the per-node-column form).
@@ -567,6 +567,11 @@ def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hi
               _p(_i32(out_ptr)), _p(Wn2), _p(bn2), n, E, V, _p(column_hint) if column_hint is not None else None, _p(msg),
               _p(agg), _stream())
         return agg
+    if save:      # (agg, pre2): pre2 = the pre-activation of the second f_node layer, kept for the reverse sweep (fp32 only)
+        pre2 = torch.empty(E, V, device=bw.device, dtype=torch.float32)
+        _call("lcao_edge_node_message_agg_saving", _p(bw), _p(Ps), _p(Pt), _p(_i32(src_p)), _p(_i32(dst_p)), _p(_i32(out_ptr)),
+              _p(Wn2), _p(bn2), n, E, V, _p(column_hint) if column_hint is not None else None, _p(pre2), _p(agg), _stream())
+        return agg, pre2
     _call("lcao_edge_node_message_agg", _p(bw), _p(Ps), _p(Pt), _p(_i32(src_p)), _p(_i32(dst_p)), _p(_i32(out_ptr)), _p(Wn2),
           _p(bn2), n, E, V, _p(column_hint) if column_hint is not None else None, _p(agg), _stream())
     return agg
