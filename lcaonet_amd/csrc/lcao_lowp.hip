@@ -42,7 +42,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8v& hi, bf16x8v
 // distinct 16-B slots).  PERMUTE stores the columns in the order a chained layer delivers its inputs (see header).
 template <int PREC, bool PERMUTE>
 __device__ __forceinline__ void stage_weights_lowp(typename LowP<PREC>::T* __restrict__ planes, const float* __restrict__ W,
-                                                   int rows, int K) {
+                                                   int rows, int K, float scale = 1.0f) {
   typedef typename LowP<PREC>::T T;
   const int ld = K + 8;
   T* hi = planes;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void stage_weights_lowp(typename LowP<PREC>::T* __res
       const int s = pos >> 5, g = (pos >> 3) & 3, j = pos & 7;
       col = 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
     }
-    const float w = W[(int64_t)rr * K + col];
+    const float w = W[(int64_t)rr * K + col] * scale;
     const T h = (T)w;
     hi[rr * ld + pos] = h;
     if (PREC == PREC_BF16X3) lo[rr * ld + pos] = (T)(w - (float)h);
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_lowp(
   extern __shared__ unsigned char lds_raw[];
   T* w1p = (T*)lds_raw;
   T* w2p = w1p + NP * V * LD1;
-  stage_weights_lowp<PREC, false>(w1p, W1, V, C);
+  // log2(e) folded into the first layer (lcao_mfma.h: g(x') = SiLU(x) log2 e for x' = x log2 e, so the second layer's
+  // input and output carry the factor and it leaves through the radial multiplier): one VALU multiply less per activation
+  stage_weights_lowp<PREC, false>(w1p, W1, V, C, LCAO_LOG2E);
   stage_weights_lowp<PREC, true>(w2p, W2, V, V);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,22 +165,20 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_lowp(
       for (int s = 0; s < KS2; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          hin[s][j] = lcao_silu(h[2 * s][j]);
-          hin[s][4 + j] = lcao_silu(h[2 * s + 1][j]);
+          hin[s][j] = lcao_silu_log2e(h[2 * s][j]);
+          hin[s][4 + j] = lcao_silu_log2e(h[2 * s + 1][j]);
         }
       f32x4v o[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
       lowp_layer<PREC, KS2, MT>(w2p, V, LD2, r, q, hin, o);
-      const float w = rbrow[d];
+      const float w = rbrow[d] * LCAO_INV_LOG2E;
       const int l = l_of_d[d];
 #pragma unroll
       for (int ll = 0; ll < NL; ++ll) {
         if (l == ll) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ll][m][j] += w * lcao_silu(o[m][j]);
+          for (int m = 0; m < MT; ++m) acc[ll][m] += w * lcao_silu_log2e4(o[m]);
         }
       }
     }
