@@ -486,7 +486,8 @@ def _triplet_weights(geo: _Geo, u: Tensor, G: Tensor) -> Tensor:
     nonlinear map (c, G) -> w is one kernel with hand-written first and second derivatives: no T-long tensor passes
     through an elementwise torch op."""
     u4 = F.pad(u, (0, 1))
-    c = _SddmmFn.apply(u4, u4.unsqueeze(1), geo).squeeze(1)                    # (T,)
+    # out-edge side: the e_own owned-centre edges; in-edge side: every local edge (the same split as tbw = spmm(w, Ag))
+    c = _SddmmFn.apply(u4[: geo.e_own], u4.unsqueeze(1), geo).squeeze(1)       # (T,)
     return _TripletWeightFn.apply(c, G, geo)
 
 
