@@ -1767,6 +1767,249 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
   }
 }
 
+// The same reverse in two phases per in-edge tile, so that neither the Ag tile nor the weights are fetched twice:
+//   phase A1 the lane's Ag rows (all l, all channels: NL x KT float4) stay in registers while GEMM 1 runs over every out-edge
+//            tile; GW[l][r] of a tile is parked in a lane-private LDS column
+//   phase A2 the scalar chain of every (p, q) pair: GW read back, the weights w[l][r] written to the same slots
+//   phase B  GEMM 2 over the same out-edge tiles with the weights read back, accumulators live only here
+// Register live ranges of the Ag tile (96) and of the g_Ag accumulators (96) no longer overlap (the fused loop above needs
+// both plus the chain: 254 registers, 2 waves per SIMD, and re-reads the Ag tile for every out-edge tile).  Out-lists longer
+// than 16 NITC edges are processed in chunks; later chunks add into the g_Ag rows this wave has already written.
+#ifndef LCAO_TBWD_WAVES
+#define LCAO_TBWD_WAVES 2
+#endif
+template <int V, int NL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_WAVES, LCAO_TBWD_WAVES))) void k_triplet_bwd_split(
+    const float* __restrict__ g_tbw, const float* __restrict__ Ag, const float* __restrict__ gram,
+    const float* __restrict__ uvec_p, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_pos,
+    const int32_t* __restrict__ out_ptr, int n_nodes, float* __restrict__ g_Ag, float* __restrict__ g_gram,
+    float* __restrict__ g_uq, float* __restrict__ g_up) {
+  constexpr int KT = V / 16;
+  constexpr int NITC = 16 / NL > 8 ? 8 : 16 / NL;   // out-edge tiles per chunk: NITC x NL x 4 floats per lane parked in LDS
+  extern __shared__ float wpark[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, quarter = lane >> 4;
+  float* wl = wpark + wave * (NITC * NL * 4 * 64) + lane;   // element k of this lane: wl[64 k]
+  for (int s = blockIdx.x * 4 + wave; s < n_nodes; s += gridDim.x * 4) {
+    const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
+    const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
+    for (int it0 = 0; it0 < m_out; it0 += 16)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pi = it0 + 4 * quarter + r;
+        if (n == 0 && pi < m_out) {
+          float* o = g_up + 3 * (int64_t)(p0 + pi);
+          o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+        }
+      }
+    for (int jt = 0; jt < m_in; jt += 16) {
+      const bool qv = (jt + n) < m_in;
+      const int q = in_pos[j0 + (qv ? jt + n : 0)];
+      const float qx = uvec_p[3 * (int64_t)q], qy = uvec_p[3 * (int64_t)q + 1], qz = uvec_p[3 * (int64_t)q + 2];
+      float G[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) G[i] = gram[(int64_t)q * 10 + i];
+      float gG[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) gG[i] = 0.f;
+      float gqx = 0.f, gqy = 0.f, gqz = 0.f;
+      const float* agq = Ag + (int64_t)q * NL * V + 4 * quarter;
+      for (int ic = 0; ic < m_out; ic += 16 * NITC) {
+        asm volatile("" ::: "memory");   // the Ag tile is loaded per chunk: hoisted out of this loop it would stay live through phase B
+        const int nit = min(NITC, (m_out - ic + 15) >> 4);
+        {  // ---------------- phase A1: GEMM 1 over the out-edge tiles of this chunk, the Ag tile resident in registers
+          f32x4v xb[NL][KT];
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int a = 0; a < KT; ++a) xb[l][a] = *(const f32x4v*)(agq + l * V + 16 * a);
+          for (int t = 0; t < nit; ++t) {
+            asm volatile("" ::: "memory");
+            const int it = ic + 16 * t;
+            const int pa = p0 + min(it + n, m_out - 1);
+            const float* gta = g_tbw + (int64_t)pa * V + 4 * quarter;
+            f32x4v xa[KT];
+#pragma unroll
+            for (int a = 0; a < KT; ++a) xa[a] = *(const f32x4v*)(gta + 16 * a);
+            f32x4v gw[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) gw[l] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+              for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) gw[l] = MFMA16(xa[a][b], xb[l][a][b], gw[l]);
+            // park GW of this tile (lane-private LDS column; the chain below replaces it with the weights)
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) wl[64 * ((t * NL + l) * 4 + r)] = gw[l][r];
+          }
+        }
+        asm volatile("" ::: "memory");
+        {  // ---------------- phase A2: the scalar chain of every (p, q) pair; GW in, weights out (same LDS slots)
+          for (int t = 0; t < nit; ++t) {
+            asm volatile("" ::: "memory");
+            const int it = ic + 16 * t;
+            f32x4v gw[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) gw[l][r] = wl[64 * ((t * NL + l) * 4 + r)];
+        // ---- scalar chain for this lane's 4 pairs (p = it + 4*quarter + r, q)
+        float w[NL][4];
+        float gpx[4], gpy[4], gpz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pi = it + 4 * quarter + r;
+          const int p = p0 + min(pi, m_out - 1);
+          const bool ok = qv && pi < m_out && p != q;
+          const float px = uvec_p[3 * (int64_t)p], py = uvec_p[3 * (int64_t)p + 1], pz = uvec_p[3 * (int64_t)p + 2];
+#if 0
+          {  // diagnostic: no per-pair scalar chain
+#pragma unroll
+            for (int l = 0; l < NL; ++l) w[l][r] = ok ? gw[l][r] * G[0] : 0.f;
+            gpx[r] = gpy[r] = gpz[r] = px * qx;
+            continue;
+          }
+#endif
+          const float c = px * qx + py * qy + pz * qz;
+          float y[4], dy[4], GY[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int l = 0; l < 4; ++l) { y[l] = l < NL ? lcao_y_l0(c, l) : 0.f; dy[l] = l < NL ? lcao_y_l0_grad(c, l) : 0.f; }
+          float m = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int l2 = l; l2 < NL; ++l2) {
+              const float gv = G[gram_idx(l, l2)];
+              if (l == l2) { m += y[l] * y[l] * gv; GY[l] += gv * y[l]; }
+              else { m += 2.0f * y[l] * y[l2] * gv; GY[l] += gv * y[l2]; GY[l2] += gv * y[l]; }
+            }
+          const float mc = fmaxf(m, 0.f);
+          const bool live = mc > 1e-24f;
+          const float inv = live ? __builtin_amdgcn_rsqf(mc) : 1e12f;
+          float g_inv = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) g_inv += gw[l][r] * y[l];
+          const float g_m = (ok && live) ? -0.5f * g_inv * inv * inv * inv : 0.f;
+          float gcv = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) gcv += (gw[l][r] * inv + 2.0f * g_m * GY[l]) * dy[l];
+          gcv = ok ? gcv : 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            w[l][r] = ok ? y[l] * inv : 0.f;
+#pragma unroll
+            for (int l2 = l; l2 < NL; ++l2) gG[gram_idx(l, l2)] += g_m * (l == l2 ? y[l] * y[l] : 2.0f * y[l] * y[l2]);
+          }
+          gqx += gcv * px; gqy += gcv * py; gqz += gcv * pz;
+          gpx[r] = gcv * qx; gpy[r] = gcv * qy; gpz[r] = gcv * qz;
+        }
+        // g_up[p] += sum over the 16 in-edges of this tile (lanes n within each 16-lane row), one writer lane per row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sx = lcao_row16_sum(gpx[r]), sy = lcao_row16_sum(gpy[r]), sz = lcao_row16_sum(gpz[r]);
+          const int pi = it + 4 * quarter + r;
+          if (n == 0 && pi < m_out) {
+            float* o = g_up + 3 * (int64_t)(p0 + pi);
+            o[0] += sx; o[1] += sy; o[2] += sz;
+          }
+        }
+            // park the weights of this tile: lane-private, conflict-free
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) wl[64 * ((t * NL + l) * 4 + r)] = w[l][r];
+          }
+        }
+        asm volatile("" ::: "memory");
+        {  // ---------------- phase B: GEMM 2 over the same tiles
+          f32x4v gA[NL][KT];
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int t2 = 0; t2 < KT; ++t2) gA[l][t2] = f32x4v{0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < nit; ++t) {
+            asm volatile("" ::: "memory");
+            const int it = ic + 16 * t;
+            float w[NL][4];
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) w[l][r] = wl[64 * ((t * NL + l) * 4 + r)];
+        // ---- GEMM 2: gA[l][t] (channel row, in-edge n) += sum_p g_tbw[p][channel] w[l][p, q_n]
+        //      k-step r: quarter `quarter` contributes p = it + 4*quarter + r (B operand = w[l][r]).
+        //      V >= 64: the A operand is read as float4 (channels 64h + 4n .. +3); its four floats feed the four channel
+        //      tiles 4h + j, so tile 4h + j holds channels 64h + 4i + j in its rows i (a permuted tiling that the store
+        //      below undoes) — 2 x 16-B loads per k-step instead of 8 x 4-B.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pr = p0 + min(it + 4 * quarter + r, m_out - 1);
+          if constexpr (V >= 64) {
+            const float* gtr = g_tbw + (int64_t)pr * V + 4 * n;
+#if 0
+            {
+              const f32x4v av = *(const f32x4v*)(gtr);
+#pragma unroll
+              for (int l = 0; l < NL; ++l) gA[l][0] = MFMA16(av[0], w[l][r], gA[l][0]);
+            }
+#else
+#pragma unroll
+            for (int h = 0; h < V / 64; ++h) {
+              const f32x4v av = *(const f32x4v*)(gtr + 64 * h);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) gA[l][4 * h + j] = MFMA16(av[j], w[l][r], gA[l][4 * h + j]);
+            }
+#endif
+          } else {
+            const float* gtr = g_tbw + (int64_t)pr * V + n;
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+              const float av = gtr[16 * t];
+#pragma unroll
+              for (int l = 0; l < NL; ++l) gA[l][t] = MFMA16(av, w[l][r], gA[l][t]);
+            }
+          }
+        }
+          }
+          // rows of q: written by the first chunk, added to by later ones (out-lists longer than 16 NITC edges)
+          if (qv) {
+            static_assert(V >= 64, "the split kernel serves V in {64, 128}");
+            float* go = g_Ag + (int64_t)q * NL * V + 16 * quarter;
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+              for (int h = 0; h < V / 64; ++h)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                  f32x4v v = f32x4v{gA[l][4 * h][rr], gA[l][4 * h + 1][rr], gA[l][4 * h + 2][rr], gA[l][4 * h + 3][rr]};
+                  float* dst = go + l * V + 64 * h + 4 * rr;
+                  if (ic > 0) v += *(const f32x4v*)dst;
+                  *(f32x4v*)dst = v;
+                }
+          }
+        }
+      }
+      // ---- this in-tile is complete: reduce the per-lane partials over the four quarters, write the scalars of q
+#pragma unroll
+      for (int i = 0; i < 10; ++i) { gG[i] += __shfl_xor(gG[i], 16); gG[i] += __shfl_xor(gG[i], 32); }
+      gqx += __shfl_xor(gqx, 16); gqx += __shfl_xor(gqx, 32);
+      gqy += __shfl_xor(gqy, 16); gqy += __shfl_xor(gqy, 32);
+      gqz += __shfl_xor(gqz, 16); gqz += __shfl_xor(gqz, 32);
+      if (qv && quarter == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) g_gram[(int64_t)q * 10 + i] = gG[i];
+        g_uq[3 * (int64_t)q] = gqx; g_uq[3 * (int64_t)q + 1] = gqy; g_uq[3 * (int64_t)q + 2] = gqz;
+      }
+    }
+  }
+}
+
 extern "C" int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const float* gram, const float* uvec_p,
                                      const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr,
                                      int64_t n_nodes, int64_t n_edges, int V, int n_l, float* g_Ag, float* g_gram,
@@ -1782,8 +2025,21 @@ extern "C" int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const 
   int64_t groups = (n_nodes + 3) / 4;
   int64_t cap = (int64_t)lcao_num_cu() * 8;
   if (groups > cap) groups = cap;
+  // V >= 64: the two-phase kernel (weights parked in LDS between the phases); LCAO_TBWD_FUSED=1 keeps the single-loop one (A/B)
+  static int fused_only = -1;
+  if (fused_only < 0) { const char* e_ = getenv("LCAO_TBWD_FUSED"); fused_only = (e_ && atoi(e_)) ? 1 : 0; }
 #define TBM_CASE(V_, NL_)                                                                                          \
   if (V == V_ && n_l == NL_) {                                                                                     \
+    if (V_ >= 64 && !fused_only) {                                                                                 \
+      constexpr int NITC_ = 16 / NL_ > 8 ? 8 : 16 / NL_;                                                           \
+      const size_t lds_ = size_t(4) * NITC_ * NL_ * 4 * 64 * sizeof(float);                                        \
+      static bool done_ = false;                                                                                   \
+      int rc_ = set_lds_attr(k_triplet_bwd_split<(V_ >= 64 ? V_ : 64), NL_>, lds_, done_);                         \
+      if (rc_ != LCAO_OK) return rc_;                                                                              \
+      hipLaunchKernelGGL((k_triplet_bwd_split<(V_ >= 64 ? V_ : 64), NL_>), dim3((unsigned)groups), dim3(256), lds_, st, \
+                         g_tbw, Ag, gram, uvec_p, in_ptr, in_pos, out_ptr, (int)n_nodes, g_Ag, g_gram, g_uq, g_up);  \
+      return lcao_launch_status();                                                                                 \
+    }                                                                                                              \
     hipLaunchKernelGGL((k_triplet_bwd_mfma<V_, NL_>), dim3((unsigned)groups), dim3(256), 0, st, g_tbw, Ag, gram, uvec_p, \
                        in_ptr, in_pos, out_ptr, (int)n_nodes, g_Ag, g_gram, g_uq, g_up);                           \
     return lcao_launch_status();                                                                                   \
