@@ -137,6 +137,27 @@ def test_cfg5_molecules_autograd_forces_vs_oracle(dev):
     assert float(force.sum(0).abs().max()) <= 1e-4 * float(force.abs().max())      # momentum conservation
 
 
+@pytest.mark.parametrize("V", [64, 32])
+def test_dense_cluster_degree_89_forces_vs_oracle(dev, V):
+    """A degree no other case reaches: 90 atoms inside a 2.8 A cube, every pair within the cutoff (89 neighbours each,
+    8 010 edges, 705 k triplets).  Exercises the second 64-wide in-edge block of lcao_triplet_gemm, the chunked out-lists of the
+    three-phase triplet backward (> 80 out-edges at n_l = 3: later chunks add into rows already written) and six-tile nodes
+    in every per-node kernel.  Energy and autograd forces against the fp64 oracle."""
+    from lcaonet_amd.data.synthetic import random_molecules
+    kw = dict(emb_size=32, emb_size_coeff=V, emb_size_conv=V, n_interaction=2, cutoff=5.0, regress_forces=True,
+              direct_forces=False)
+    m, sd = _random_model(dev, 91, **kw)
+    g = random_molecules(1, 90, 2.8, 0.99 * 5.0, seed=12, device=dev)
+    assert g["edge_index"].shape[1] == 90 * 89 and m.n_l == 3
+    gc = {k: v.cpu() for k, v in g.to_dict().items() if k in ("z", "pos", "edge_index", "edge_shift", "lattice", "batch")}
+    want, wforce = O.forward(sd, _ocfg({**kw, "rbf_type": "hydrogen"}), gc, dtype=torch.float64)
+    out, force = m(g)
+    assert relerr(out, want.detach()) <= TOL
+    assert relerr(force, wforce.detach()) <= 5 * TOL
+    fm, _ = _random_model(dev, 91, **{**kw, "regress_forces": False})          # the forward-only pipeline on the same graph
+    assert relerr(fm(g), want.detach()) <= TOL
+
+
 def test_cfg5_molecules_direct_forces_vs_oracle(dev):
     """The direct-force head on the same shape (the reference's default for regress_forces)."""
     from lcaonet_amd.data.synthetic import random_molecule_batch

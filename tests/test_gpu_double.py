@@ -128,9 +128,13 @@ def test_trip_bilinear_family_is_consistent(dev):
     from lcaonet_amd.data.synthetic import random_periodic_cells
     from lcaonet_amd.model import LCAONet
     from lcaonet_amd.model.double import _Geo
-    g = random_periodic_cells(2, 12, 6.0, 0.99 * 4.5, seed=3).to(dev)
-    for V, n_l, max_z in ((48, 3, 36), (128, 2, 10), (200, 4, 96), (128, 4, 36), (50, 3, 36), (32, 1, 36)):
-        m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=V, n_interaction=1, cutoff=4.5, max_z=max(max_z, 36)).to(dev)
+    from lcaonet_amd.data.synthetic import random_molecules
+    g_small = random_periodic_cells(2, 12, 6.0, 0.99 * 4.5, seed=3).to(dev)
+    g_dense = random_molecules(1, 70, 2.8, 0.99 * 5.0, seed=2, device=dev)        # 69 neighbours each: five 16-wide tiles
+    for V, n_l, max_z, g in ((48, 3, 36, g_small), (128, 2, 10, g_small), (200, 4, 96, g_small), (128, 4, 36, g_small),
+                             (50, 3, 36, g_small), (32, 1, 36, g_small), (128, 3, 36, g_dense), (64, 4, 36, g_dense)):
+        m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=V, n_interaction=1, cutoff=5.0 if g is g_dense else 4.5,
+                    max_z=max(max_z, 36)).to(dev)
         geo = _Geo(m, g)
         geo.n_l = n_l
         E, T = geo.E, geo.T
