@@ -406,6 +406,19 @@ int lcao_silu_levels(int level, const float* x, const float* g, const float* h, 
 int lcao_rownorm_levels(int level, const float* x, const float* g, const float* k, int64_t n_rows, int V, float eps,
                         float* out0, float* out1, void* stream);
 
+/* f(a, b) = a (c0 + b), elementwise — the message product bw * h2 (c0 = 0) and the injection B (1 + ft) (c0 = 1) — with the
+ * same derivative levels: 0: out0 = f;  1 (cotangent g): out0 = d/da, out1 = d/db;  2 (cotangents ha, hb of level 1's
+ * outputs): out0 = d/dg, out1 = d/da, out2 = d/db.  16-byte aligned operands. */
+int lcao_mulp_levels(int level, const float* a, const float* b, const float* g, const float* ha, const float* hb, float c0,
+                     int64_t n, float* out0, float* out1, float* out2, void* stream);
+
+/* The gated copy Ag = A * gate[src] (lcaonet.py:186, broadcast over l) and B = sum_l A (:200-203) with the terms of their two
+ * derivative levels:  bcast_fma: out[e,l,:] = X1[e,l,:] y1[e,:] (+ X2[e,l,:] y2[e,:]) (+ z[e,:]);
+ *                     lsum_mul : out[e,:] = sum_l X[e,l,:] (Y[e,l,:] or 1).   X (E, L, V), y / z / out (E, V); V % 4 == 0. */
+int lcao_bcast_fma(const float* X1, const float* y1, const float* X2 /* nullable, with y2 */, const float* y2,
+                   const float* z /* nullable */, int64_t n_edges, int L, int V, float* out, void* stream);
+int lcao_lsum_mul(const float* X, const float* Y /* nullable */, int64_t n_edges, int L, int V, float* out, void* stream);
+
 /* The per-edge Gram matrix of lcaonet.py:179-184 (|sum_l Y_l A[q,l,:]|^2 = Y^T G_q Y, G_q = A_q A_q^T) as a second closed
  * family:  rowgram: out[e,l,m] = sum_v X[e,l,v] Y[e,m,v]   (E, n_l, n_l)
  *          rowmix : out[e,l,v] = sum_m S[e,l,m] A[e,m,v]   (E, n_l, V); trans != 0 reads S[e,m,l]

@@ -611,6 +611,83 @@ __global__ void k_silu_levels(const float* __restrict__ x, const float* __restri
   }
 }
 
+// f(a, b) = a (c0 + b): the message product bw * h2 (c0 = 0, lcaonet.py:209-211) and the two-body injection B (1 + ft)
+// (c0 = 1, lcaonet.py:192-196) with both derivative levels:
+//   level 0: out0 = a (c0 + b)     level 1 (cotangent g): out0 = g (c0 + b) [d/da], out1 = g a [d/db]
+//   level 2 (cotangents ha, hb of level 1's outputs): out0 = ha (c0 + b) + hb a [d/dg], out1 = hb g [d/da], out2 = ha g [d/db]
+template <int LEVEL>
+__global__ void k_mulp_levels(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                              const float* __restrict__ ha, const float* __restrict__ hb, float c0, int64_t n,
+                              float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const f32x4v av = *(const f32x4v*)(a + i), bv = *(const f32x4v*)(b + i) + c0;
+      if (LEVEL == 0) *(f32x4v*)(o0 + i) = av * bv;
+      if (LEVEL == 1) {
+        const f32x4v gv = *(const f32x4v*)(g + i);
+        *(f32x4v*)(o0 + i) = gv * bv;
+        *(f32x4v*)(o1 + i) = gv * av;
+      }
+      if (LEVEL == 2) {
+        const f32x4v gv = *(const f32x4v*)(g + i), hav = *(const f32x4v*)(ha + i), hbv = *(const f32x4v*)(hb + i);
+        *(f32x4v*)(o0 + i) = hav * bv + hbv * av;
+        *(f32x4v*)(o1 + i) = hbv * gv;
+        *(f32x4v*)(o2 + i) = hav * gv;
+      }
+    } else {
+      for (int64_t k = i; k < n; ++k) {
+        const float av = a[k], bv = b[k] + c0;
+        if (LEVEL == 0) o0[k] = av * bv;
+        if (LEVEL == 1) { o0[k] = g[k] * bv; o1[k] = g[k] * av; }
+        if (LEVEL == 2) { o0[k] = ha[k] * bv + hb[k] * av; o1[k] = hb[k] * g[k]; o2[k] = ha[k] * g[k]; }
+      }
+    }
+  }
+}
+
+// The gated copy of lcaonet.py:186 (Ag = A * gate[src], broadcast over l) and the sum over l (B = sum_l A, :200-203) with
+// everything their two derivative levels need, as two primitives over (E, L, V) / (E, V) operands:
+//   bcast_fma:  out[e,l,:] = X1[e,l,:] y1[e,:]  (+ X2[e,l,:] y2[e,:])  (+ z[e,:])
+//   lsum_mul :  out[e,:]   = sum_l X[e,l,:] (Y[e,l,:] or 1)
+__global__ void k_bcast_fma(const float* __restrict__ X1, const float* __restrict__ y1, const float* __restrict__ X2,
+                            const float* __restrict__ y2, const float* __restrict__ z, int64_t n_edges, int L, int V4,
+                            float* __restrict__ out) {
+  const int64_t total = n_edges * V4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t e = i / V4;
+    const int c = (int)(i - e * V4);
+    const int64_t yo = (e * V4 + c) * 4;
+    const f32x4v a1 = *(const f32x4v*)(y1 + yo);
+    const f32x4v a2 = y2 ? *(const f32x4v*)(y2 + yo) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    const f32x4v zz = z ? *(const f32x4v*)(z + yo) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+      const int64_t xo = ((e * L + l) * V4 + c) * 4;
+      f32x4v v = *(const f32x4v*)(X1 + xo) * a1 + zz;
+      if (X2) v += *(const f32x4v*)(X2 + xo) * a2;
+      *(f32x4v*)(out + xo) = v;
+    }
+  }
+}
+
+__global__ void k_lsum_mul(const float* __restrict__ X, const float* __restrict__ Y, int64_t n_edges, int L, int V4,
+                           float* __restrict__ out) {
+  const int64_t total = n_edges * V4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t e = i / V4;
+    const int c = (int)(i - e * V4);
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+      const int64_t xo = ((e * L + l) * V4 + c) * 4;
+      const f32x4v x = *(const f32x4v*)(X + xo);
+      acc += Y ? x * *(const f32x4v*)(Y + xo) : x;
+    }
+    *(f32x4v*)(out + (e * V4 + c) * 4) = acc;
+  }
+}
+
 template <int R, int LEVEL>
 __global__ void k_rownorm_levels(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ k,
                                  int64_t n_rows, int V, float eps, float* __restrict__ o0, float* __restrict__ o1) {
@@ -1003,5 +1080,41 @@ extern "C" int lcao_radial_levels(int level, const float* r, const float* g, con
   else if (level == 1) RL(1);
   else RL(2);
 #undef RL
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_mulp_levels(int level, const float* a, const float* b, const float* g, const float* ha, const float* hb,
+                                float c0, int64_t n, float* out0, float* out1, float* out2, void* stream) {
+  if (n < 0 || level < 0 || level > 2) return LCAO_ERR_INVALID;
+  if (n == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(a); LCAO_CHECK_PTR(b); LCAO_CHECK_PTR(out0);
+  if (level >= 1) { LCAO_CHECK_PTR(g); LCAO_CHECK_PTR(out1); }
+  if (level == 2) { LCAO_CHECK_PTR(ha); LCAO_CHECK_PTR(hb); LCAO_CHECK_PTR(out2); }
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out0)) & 15) return LCAO_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks((n + 3) / 4, 256, 65536)), block(256);
+  if (level == 0) hipLaunchKernelGGL(k_mulp_levels<0>, grid, block, 0, st, a, b, g, ha, hb, c0, n, out0, out1, out2);
+  else if (level == 1) hipLaunchKernelGGL(k_mulp_levels<1>, grid, block, 0, st, a, b, g, ha, hb, c0, n, out0, out1, out2);
+  else hipLaunchKernelGGL(k_mulp_levels<2>, grid, block, 0, st, a, b, g, ha, hb, c0, n, out0, out1, out2);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_bcast_fma(const float* X1, const float* y1, const float* X2, const float* y2, const float* z,
+                              int64_t n_edges, int L, int V, float* out, void* stream) {
+  if (n_edges < 0 || L < 1 || V <= 0 || V % 4) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(X1); LCAO_CHECK_PTR(y1); LCAO_CHECK_PTR(out);
+  if ((X2 == nullptr) != (y2 == nullptr)) return LCAO_ERR_INVALID;
+  hipLaunchKernelGGL(k_bcast_fma, dim3(lcao_blocks(n_edges * (V / 4), 256, 65536)), dim3(256), 0, (hipStream_t)stream, X1, y1,
+                     X2, y2, z, n_edges, L, V / 4, out);
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_lsum_mul(const float* X, const float* Y, int64_t n_edges, int L, int V, float* out, void* stream) {
+  if (n_edges < 0 || L < 1 || V <= 0 || V % 4) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(X); LCAO_CHECK_PTR(out);
+  hipLaunchKernelGGL(k_lsum_mul, dim3(lcao_blocks(n_edges * (V / 4), 256, 65536)), dim3(256), 0, (hipStream_t)stream, X, Y,
+                     n_edges, L, V / 4, out);
   return lcao_launch_status();
 }

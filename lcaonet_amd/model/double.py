@@ -443,6 +443,94 @@ _SiluFn, _SiluBwdFn = _levels_functions(ops.silu_levels)
 _RowNormFn, _RowNormBwdFn = _levels_functions(ops.rownorm_levels)
 
 
+class _GateSumFn(Function):
+    """(Ag, B) = (A * ge[:, None, :], A.sum(1)) — the gated copy of lcaonet.py:186 and the two-body sum of :200-203 — from two
+    kernels (csrc/lcao_double.hip: bcast_fma, lsum_mul); the backward is a Function again (second order from the same two)."""
+
+    @staticmethod
+    def forward(ctx, A, ge):
+        ctx.save_for_backward(A, ge)
+        return ops.bcast_fma(A, ge), ops.lsum_mul(A)
+
+    @staticmethod
+    def backward(ctx, gAg, gB):
+        A, ge = ctx.saved_tensors
+        gAg = torch.zeros_like(A) if gAg is None else gAg.contiguous()
+        gB = torch.zeros_like(ge) if gB is None else gB.contiguous()
+        return _GateSumBwdFn.apply(gAg, gB, A, ge)
+
+
+class _GateSumBwdFn(Function):
+    @staticmethod
+    def forward(ctx, gAg, gB, A, ge):
+        ctx.save_for_backward(gAg, A, ge)
+        return ops.bcast_fma(gAg, ge, z=gB), ops.lsum_mul(gAg, A)          # dA, d(ge)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hA, hg):
+        gAg, A, ge = ctx.saved_tensors
+        hA = torch.zeros_like(A) if hA is None else hA.contiguous()
+        hg = torch.zeros_like(ge) if hg is None else hg.contiguous()
+        return (ops.bcast_fma(hA, ge, A, hg),        # d/dgAg = hA ge + A hg
+                ops.lsum_mul(hA),                    # d/dgB
+                ops.bcast_fma(gAg, hg),              # d/dA
+                ops.lsum_mul(hA, gAg))               # d/dge
+
+
+class _PairPreFn(Function):
+    """pre1[p] = Ps[src(p)] + Pt[dst(p)] in one kernel (csrc: lcao_pair_pre); its adjoint is two sorted-segment scatters,
+    which are differentiable Functions themselves."""
+
+    @staticmethod
+    def forward(ctx, Ps, Pt, geo):
+        ctx.geo = geo
+        c = geo.ctx
+        return ops.pair_pre(Ps, Pt, c.src_p[: geo.e_own], c.dst_p[: geo.e_own])
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return scatter_sum(g, ctx.geo.src_o), scatter_sum(g, ctx.geo.dst_o), None
+
+
+class _MulPFn(Function):
+    """a (c0 + b) elementwise (csrc/lcao_double.hip::k_mulp_levels) with its first and second derivatives as single kernels."""
+
+    @staticmethod
+    def forward(ctx, a, b, c0):
+        ctx.c0 = c0
+        ctx.save_for_backward(a, b)
+        return ops.mulp_levels(0, a, b, c0)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga, gb = _MulPBwdFn.apply(g.contiguous(), a, b, ctx.c0)
+        return ga, gb, None
+
+
+class _MulPBwdFn(Function):
+    @staticmethod
+    def forward(ctx, g, a, b, c0):
+        ctx.c0 = c0
+        ctx.save_for_backward(g, a, b)
+        return ops.mulp_levels(1, a, b, c0, g=g)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ha, hb):
+        g, a, b = ctx.saved_tensors
+        ha = torch.zeros_like(a) if ha is None else ha.contiguous()
+        hb = torch.zeros_like(a) if hb is None else hb.contiguous()
+        dg, da, db = ops.mulp_levels(2, a, b, ctx.c0, g=g, ha=ha, hb=hb)
+        return dg, da, db, None
+
+
+def mulp(a: Tensor, b: Tensor, c0: float) -> Tensor:
+    return _MulPFn.apply(a.contiguous(), b.contiguous(), float(c0))
+
+
 def _activation(module, x: Tensor) -> Tensor:
     return _SiluFn.apply(x.contiguous()) if type(module) is torch.nn.SiLU else module(x)
 
@@ -524,23 +612,27 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
             Ac = _ContractFn.apply(rb, Tf[..., :V], geo)
             Av = _ContractFn.apply(rb, Tf[..., V:] * mask_pair, geo)
             A, B, Bv = Ac + Av, Ac.sum(dim=1), Av.sum(dim=1)
+            Ag = A * gather(gate, geo.src).unsqueeze(1)
         else:
             A = _ContractFn.apply(rb, Tf, geo)
-            B, Bv = A.sum(dim=1), None
-        Ag = A * gather(gate, geo.src).unsqueeze(1)
+            if V % 4 == 0:
+                Ag, B = _GateSumFn.apply(A.contiguous(), gather(gate, geo.src))
+            else:
+                Ag, B = A * gather(gate, geo.src).unsqueeze(1), A.sum(dim=1)
+            Bv = None
         G = _GramFn.apply(A.contiguous())
         tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)               # (e_own, V)
         ft = dense(tbw, layer.f_three[0].weight)
         B = B[: geo.e_own]
         if Bv is None:
-            lw_in = B + B * ft
+            lw_in = mulp(B, ft, 1.0)                                          # B (1 + ft)
         else:
             Bv = Bv[: geo.e_own]
             lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
         bw = dense(_RowNormFn.apply(lw_in.contiguous()), layer.basis_weight.weight)       # F.normalize(dim=-1)
-        h1 = _activation(layer.f_node[1], gather(Ps, geo.src_o) + gather(Pt, geo.dst_o))
+        h1 = _activation(layer.f_node[1], _PairPreFn.apply(Ps.contiguous(), Pt.contiguous(), geo))
         h2 = _activation(layer.f_node[3], dense(h1, layer.f_node[2].weight, layer.f_node[2].bias))
-        x = x[:n_own] + dense(scatter_sum(bw * h2, geo.agg), layer.out_weight.weight)
+        x = x[:n_own] + dense(scatter_sum(mulp(bw, h2, 0.0), geo.agg), layer.out_weight.weight)
     prop = _mlp(model.out_layer.out_lin, x)
     batch = graph.get(GraphKeys.Batch_idx)
     ext = model.out_layer.is_extensive

@@ -826,6 +826,49 @@ def silu_levels(level: int, x, g=None, h=None):
     return o0 if level < 2 else (o0, o1)
 
 
+def bcast_fma(X1, y1, X2=None, y2=None, z=None):
+    """out[e,l,:] = X1[e,l,:] y1[e,:] (+ X2[e,l,:] y2[e,:]) (+ z[e,:]);  X (E, L, V), y / z (E, V)."""
+    X1, y1 = _f32(X1, "X1"), _f32(y1, "y1")
+    E, L, V = X1.shape
+    opt = lambda t, shape: None if t is None else _f32(t)
+    X2, y2, z = opt(X2, None), opt(y2, None), opt(z, None)
+    for t, shape in ((y1, (E, V)), (X2, (E, L, V)), (y2, (E, V)), (z, (E, V))):
+        if t is not None and tuple(t.shape) != shape:
+            raise ValueError(f"bcast_fma: operand {tuple(t.shape)} where {shape} is expected")
+    out = torch.empty_like(X1)
+    p = lambda t: _p(t) if t is not None else None
+    _call("lcao_bcast_fma", _p(X1), _p(y1), p(X2), p(y2), p(z), E, L, V, _p(out), _stream())
+    return out
+
+
+def lsum_mul(X, Y=None):
+    """out[e,:] = sum_l X[e,l,:] (Y[e,l,:] or 1)."""
+    X = _f32(X, "X")
+    E, L, V = X.shape
+    Y = None if Y is None else _f32(Y, "Y")
+    if Y is not None and Y.shape != X.shape:
+        raise ValueError("lsum_mul: X and Y must have one shape")
+    out = torch.empty(E, V, device=X.device, dtype=torch.float32)
+    _call("lcao_lsum_mul", _p(X), _p(Y) if Y is not None else None, E, L, V, _p(out), _stream())
+    return out
+
+
+def mulp_levels(level: int, a, b, c0: float, g=None, ha=None, hb=None):
+    """a (c0 + b) with closed-form derivative levels (csrc/lcao_double.hip): 0 -> f; 1 -> (g (c0 + b), g a);
+    2 -> (ha (c0 + b) + hb a, hb g, ha g)."""
+    a, b = _f32(a, "a"), _f32(b, "b")
+    ts = [None if t is None else _f32(t) for t in (g, ha, hb)]
+    for t in [b] + [t for t in ts if t is not None]:
+        if t.shape != a.shape:
+            raise ValueError("mulp_levels: operands must have one shape")
+    outs = [torch.empty_like(a) for _ in range(level + 1)]
+    opt = lambda t: _p(t) if t is not None else None
+    po = [_p(o) for o in outs] + [None] * (2 - level)
+    _call("lcao_mulp_levels", level, _p(a), _p(b), opt(ts[0]), opt(ts[1]), opt(ts[2]), float(c0), a.numel(), po[0], po[1], po[2],
+          _stream())
+    return outs[0] if level == 0 else tuple(outs)
+
+
 def rownorm_levels(level: int, x, g=None, k=None, eps: float = 1e-12):
     """x / max(|x|, eps) along the last dim with closed-form derivatives; levels as silu_levels."""
     x = _f32(x, "x")

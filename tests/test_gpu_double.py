@@ -286,6 +286,48 @@ def test_radial_levels_first_and_second_derivatives(dev, rbf_type, cutoff_type):
     assert math.isfinite(float(got[2].abs().max()))
 
 
+def test_product_primitives_first_and_second_derivatives(dev):
+    """model/double.py _MulPFn (a (c0 + b): the message product and the injection B (1 + ft)), _GateSumFn (gated copy +
+    sum over l) and _PairPreFn (Ps[src] + Pt[dst]): value, gradient and gradient-of-gradient against the same expressions
+    from fp64 tensor ops under autograd."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import LCAONet
+    from lcaonet_amd.model.double import _Geo, _GateSumFn, _PairPreFn, mulp
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen).to(dev)
+
+    def chain(f, inputs, R, Hs):
+        xs = [x.clone().requires_grad_(True) for x in inputs]
+        Rr = [r.clone().requires_grad_(True) for r in R]
+        outs = f(*xs)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        g1 = torch.autograd.grad(sum((o * r).sum() for o, r in zip(outs, Rr)), xs, create_graph=True)
+        g2 = torch.autograd.grad(sum((g * h).sum() for g, h in zip(g1, Hs)), xs + Rr, allow_unused=True)
+        g2 = [torch.zeros_like(t) if g is None else g for g, t in zip(g2, xs + Rr)]
+        return [o.detach() for o in outs] + [g.detach() for g in g1] + list(g2)
+    dbl = lambda ts: [t.double() for t in ts]
+    for c0 in (0.0, 1.0):
+        for n in (5, 1030 * 48):
+            a, b, R, Ha, Hb = rnd(n), rnd(n), rnd(n), rnd(n), rnd(n)
+            got = chain(lambda x, y: mulp(x, y, c0), [a, b], [R], [Ha, Hb])
+            want = chain(lambda x, y: x * (c0 + y), dbl([a, b]), dbl([R]), dbl([Ha, Hb]))
+            assert all(relerr(g, w) <= 2e-6 for g, w in zip(got, want)), (c0, n)
+    for E, L, V in ((7, 1, 16), (301, 3, 128), (64, 4, 48)):
+        A, ge = rnd(E, L, V), rnd(E, V)
+        R, Hs = [rnd(E, L, V), rnd(E, V)], [rnd(E, L, V), rnd(E, V)]
+        got = chain(lambda x, y: _GateSumFn.apply(x, y), [A, ge], R, Hs)
+        want = chain(lambda x, y: (x * y.unsqueeze(1), x.sum(1)), dbl([A, ge]), dbl(R), dbl(Hs))
+        assert all(relerr(g, w) <= 2e-6 for g, w in zip(got, want)), (E, L, V)
+    g = random_periodic_cells(2, 12, 6.0, 0.99 * 4.5, seed=3).to(dev)
+    m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=32, n_interaction=1, cutoff=4.5).to(dev)
+    geo = _Geo(m, g)
+    Ps, Pt = rnd(geo.N, 32), rnd(geo.N, 32)
+    R, Hs = [rnd(geo.E, 32)], [rnd(geo.N, 32), rnd(geo.N, 32)]
+    got = chain(lambda x, y: _PairPreFn.apply(x, y, geo), [Ps, Pt], R, Hs)
+    want = chain(lambda x, y: x[geo.src.idx] + y[geo.dst.idx], dbl([Ps, Pt]), dbl(R), dbl(Hs))
+    assert all(relerr(g_, w) <= 2e-6 for g_, w in zip(got, want))
+
+
 def test_rowgram_family_first_and_second_derivatives(dev):
     """csrc/lcao_double.hip rowgram / rowmix (the per-edge Gram matrix of lcaonet.py:179-184 and its derivatives): values
     against fp64 einsums, and gradient + gradient-of-gradient through model/double.py's Functions against autograd of
