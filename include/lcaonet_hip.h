@@ -279,10 +279,12 @@ int lcao_edge_node_message(const float* bw, const float* Ps, const float* Pt, co
  * rows (edges sorted by centre; out_ptr from lcao_build_csr; a wave owns whole centre nodes, DPP segmented sums, no
  * atomics, bitwise reproducible).  msg (E, V) is never written.  agg (n_nodes, V) is fully written (zero for nodes without
  * edges).  n_edges = out_ptr[n_nodes].
- * column_hint (device, 1 x int32 from lcao_node_column_hint, or NULL): when it reads 1 the sum is done by the
- * "one centre node per MFMA column" form instead (16 nodes per wave, step t = their t-th out-edges, per-lane accumulation:
- * a third of the VALU work; used when the degrees of consecutive nodes are even enough that the padding stays < 10 %).
- * The choice is made on the device — no host synchronisation; both forms are deterministic. */
+ * column_hint (device, (1 + n_nodes) x int32 from lcao_node_column_hint, or NULL): when its first word reads 1 or 2 the sum
+ * is done by the "one centre node per MFMA column" form instead (16 nodes per wave, step t = their t-th out-edges, per-lane
+ * accumulation: a third of the VALU work).  1: groups of 16 consecutive nodes; 2: groups of 16 nodes of similar degree in
+ * the order stored in words 1 .. n_nodes (graphs whose neighbouring nodes have uneven degrees); 0: padding would cost more
+ * than 10 % either way and the edge-tiled form runs.  The choice is made on the device — no host synchronisation; all
+ * forms give the same bits for a node whatever the grouping. */
 int lcao_edge_node_message_agg(const float* bw, const float* Ps, const float* Pt, const int32_t* src_p,
                                const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
                                int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* agg,
@@ -292,7 +294,7 @@ int lcao_edge_node_message_agg_saving(const float* bw, const float* Ps, const fl
                                       const int32_t* dst_p, const int32_t* out_ptr, const float* Wn2, const float* bn2,
                                       int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* pre2,
                                       float* agg, void* stream);
-int lcao_node_column_hint(const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int32_t* hint, void* stream);
+int lcao_node_column_hint(const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int32_t* hint /* 1 + n_nodes */, void* stream);
 
 /* The same two kernels for a forward pass that will be differentiated (autograd forces, training): they also keep
  * ft = tbw W3^T (E,V) and pre2 = SiLU(Ps[s]+Pt[t]) Wn2^T + bn2 (E,V), the two intermediates the reverse sweep needs. */

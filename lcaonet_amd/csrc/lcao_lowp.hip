@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols_lowp(
   constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
   extern __shared__ unsigned char lds_raw[];
   if (hint && *hint == 0) return;
+  const bool by_degree = hint && *hint == 2;
   T* wp = (T*)lds_raw;
   stage_weights_lowp<PREC, false>(wp, Wn2, V, V);
   __syncthreads();
@@ -446,7 +447,8 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols_lowp(
   const int n_groups = (n_nodes + 15) >> 4;
   for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
     const bool node_ok = 16 * g + r < n_nodes;
-    const int s = node_ok ? 16 * g + r : n_nodes - 1;
+    const int slot = node_ok ? 16 * g + r : n_nodes - 1;
+    const int s = by_degree ? hint[1 + slot] : slot;          // nodes grouped by degree (lcao_node_column_hint, mode 2)
     const int b = out_ptr[s];
     const int deg = node_ok ? out_ptr[s + 1] - b : 0;
     int Tn = deg;

@@ -822,6 +822,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols(
   constexpr int MT = V / 16;
   extern __shared__ float lds[];
   if (hint && *hint == 0) return;   // uneven degrees: the edge-tiled kernel has produced agg
+  const bool by_degree = hint && *hint == 2;
   stage_weights(lds, Wn2, V, V, V);
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -830,7 +831,8 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols(
   const int n_groups = (n_nodes + 15) >> 4;
   for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
     const bool node_ok = 16 * g + r < n_nodes;
-    const int s = node_ok ? 16 * g + r : n_nodes - 1;
+    const int slot = node_ok ? 16 * g + r : n_nodes - 1;
+    const int s = by_degree ? hint[1 + slot] : slot;          // hint[0] == 2: nodes grouped by degree (lcao_node_column_hint)
     const int b = out_ptr[s];
     const int deg = node_ok ? out_ptr[s + 1] - b : 0;
     int T = deg;   // max over the 16 columns (the four quarters hold the same 16 values)
@@ -890,24 +892,73 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols(
 }
 
 // hint[0] = 1 when running every group of 16 consecutive centre nodes for its maximum degree costs at most 10 % more
-// 16-edge steps than the edge list itself has (one workgroup; a few microseconds; built once per edge list)
+// 16-edge steps than the edge list itself has.  Otherwise the nodes are grouped by degree instead: hint[1 .. n_nodes] gets
+// a node order sorted by degree (counting sort; the order inside a degree class is arbitrary, which cannot change any result:
+// a node's sum depends on its own column only) and hint[0] = 2 when THAT grouping stays within the 10 % — molecules of
+// mixed size, surfaces.  0: neither (a few hubs among many low-degree nodes): the edge-tiled kernel runs.
+// One workgroup; a few microseconds when the natural order passes, three passes over the nodes otherwise; built once per
+// edge list.
+#define LCAO_HINT_BINS 1024
 __global__ __launch_bounds__(1024) void k_node_column_hint(const int32_t* __restrict__ out_ptr, int n_nodes, int n_edges,
                                                           int32_t* __restrict__ hint) {
   __shared__ long long part[1024];
-  long long steps = 0;
+  __shared__ int bins[LCAO_HINT_BINS];
+  __shared__ int verdict;
   const int n_groups = (n_nodes + 15) >> 4;
+  auto block_sum = [&](long long v) {
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+    }
+    const long long total = part[0];
+    __syncthreads();
+    return total;
+  };
+  auto fits = [&](long long steps) { return steps * 160 <= (long long)n_edges * 11 + 160; };
+  long long steps = 0;
   for (int g = threadIdx.x; g < n_groups; g += 1024) {
     int mx = 0;
     for (int i = 16 * g; i < min(16 * g + 16, n_nodes); ++i) mx = max(mx, out_ptr[i + 1] - out_ptr[i]);
     steps += mx;
   }
-  part[threadIdx.x] = steps;
-  __syncthreads();
-  for (int w = 512; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-    __syncthreads();
+  steps = block_sum(steps);
+  if (fits(steps)) {
+    if (threadIdx.x == 0) hint[0] = 1;
+    return;
   }
-  if (threadIdx.x == 0) hint[0] = (part[0] * 160 <= (long long)n_edges * 11 + 160) ? 1 : 0;
+  // counting sort by degree, highest first
+  for (int i = threadIdx.x; i < LCAO_HINT_BINS; i += 1024) bins[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_nodes; i += 1024) atomicAdd(&bins[min(out_ptr[i + 1] - out_ptr[i], LCAO_HINT_BINS - 1)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int d = LCAO_HINT_BINS - 1; d >= 0; --d) {
+      const int c = bins[d];
+      bins[d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  int32_t* order = hint + 1;
+  for (int i = threadIdx.x; i < n_nodes; i += 1024)
+    order[atomicAdd(&bins[min(out_ptr[i + 1] - out_ptr[i], LCAO_HINT_BINS - 1)], 1)] = i;
+  __threadfence_block();
+  __syncthreads();
+  steps = 0;
+  for (int g = threadIdx.x; g < n_groups; g += 1024) {
+    int mx = 0;
+    for (int i = 16 * g; i < min(16 * g + 16, n_nodes); ++i) {
+      const int s = order[i];
+      mx = max(mx, out_ptr[s + 1] - out_ptr[s]);
+    }
+    steps += mx;
+  }
+  steps = block_sum(steps);
+  if (threadIdx.x == 0) hint[0] = fits(steps) ? 2 : 0;
+  (void)verdict;
 }
 
 extern "C" int lcao_node_column_hint(const int32_t* out_ptr, int64_t n_nodes, int64_t n_edges, int32_t* hint, void* stream) {

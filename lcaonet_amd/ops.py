@@ -545,9 +545,10 @@ def edge_node_message(bw, Ps, Pt, src_p, dst_p, Wn2, bn2, precision="fp32", save
 
 
 def node_column_hint(out_ptr, n_edges: int) -> Tensor:
-    """(1,) int32 on the device: 1 if the per-node-column form of edge_node_message_agg pays for this edge list."""
+    """(1 + n_nodes,) int32 on the device: word 0 says whether the per-node-column form of edge_node_message_agg pays for this
+    edge list (1: consecutive nodes; 2: nodes grouped by degree, order in words 1..; 0: no)."""
     out_ptr = _i32(out_ptr)
-    hint = torch.zeros(1, device=out_ptr.device, dtype=torch.int32)
+    hint = torch.zeros(out_ptr.numel(), device=out_ptr.device, dtype=torch.int32)
     _call("lcao_node_column_hint", _p(out_ptr), out_ptr.numel() - 1, n_edges, _p(hint), _stream())
     return hint
 

@@ -914,10 +914,32 @@ def test_edge_node_message_agg_both_forms_vs_fp64(dev, V):
             assert bool((lo[form][[0, 57, 58, N - 1]] == 0).all())
         assert relerr(lo[1], lo[0]) <= 2e-6, (precision, relerr(lo[1], lo[0]))
         assert relerr(ops.edge_node_message_agg(*args, precision=precision), lo[0]) == 0.0
-    assert int(ops.node_column_hint(args[5], E)) == 0                            # degrees 0..97: padding would double the work
+    # the device-side choice.  This graph (one node of 97 among 202 of 0..40) is too small for either grouping: mode 0
+    assert int(ops.node_column_hint(args[5], E)[0]) == 0
+    # 330 nodes of degree 3..40 in random order: consecutive nodes fail, nodes grouped by degree pass -> mode 2 with a node
+    # order; the result is the same bits as mode 1 (a node's sum does not depend on which nodes share its tile)
+    N2 = 330
+    deg2 = torch.randint(3, 41, (N2,), generator=gen)
+    ptr2 = torch.zeros(N2 + 1, dtype=torch.int32)
+    ptr2[1:] = torch.cumsum(deg2, 0).to(torch.int32)
+    E2 = int(ptr2[-1])
+    src2 = torch.repeat_interleave(torch.arange(N2), deg2).to(torch.int32)
+    dst2 = torch.randint(0, N2, (E2,), generator=gen).to(torch.int32)
+    args2 = [t.to(dev) for t in (rnd(E2, V), rnd(N2, V), rnd(N2, V), src2, dst2, ptr2, W, b)]
+    hint = ops.node_column_hint(args2[5], E2)
+    assert hint.numel() == N2 + 1 and int(hint[0]) == 2
+    order = hint[1:].long().cpu()
+    assert sorted(order.tolist()) == list(range(N2)) and bool((deg2[order][:-1] >= deg2[order][1:]).all())
+    one = torch.full((1,), 1, dtype=torch.int32, device=dev)
+    for precision in ("fp32", "bf16x3", "f16"):
+        assert torch.equal(ops.edge_node_message_agg(*args2, column_hint=hint, precision=precision),
+                           ops.edge_node_message_agg(*args2, column_hint=one, precision=precision)), precision
     even = torch.arange(0, 18 * 64 + 1, 18, dtype=torch.int32, device=dev)       # 64 nodes x 18 edges
-    assert int(ops.node_column_hint(even, 18 * 64)) == 1
-    assert int(ops.node_column_hint(torch.zeros(1, dtype=torch.int32, device=dev), 0)) in (0, 1)   # empty graph: any
+    assert int(ops.node_column_hint(even, 18 * 64)[0]) == 1
+    hub = torch.zeros(402, dtype=torch.int32, device=dev)                        # one node of 3000 edges among 400 of 1: neither
+    hub[1:] = 3000 + torch.arange(401, dtype=torch.int32, device=dev)
+    assert int(ops.node_column_hint(hub, 3400)[0]) == 0
+    assert int(ops.node_column_hint(torch.zeros(1, dtype=torch.int32, device=dev), 0)[0]) in (0, 1)   # empty graph: any
 
 
 @pytest.mark.parametrize("precision", ["fp32", "f16"])

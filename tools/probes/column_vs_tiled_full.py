@@ -27,7 +27,7 @@ for name, batch, mk in (("cfg2 1000 crystals", jittered_cubic_cells(seed=1234, d
             b = model(batch, trace=tr_t, **kw).clone()
             EdgeContext.column_hint = orig
             ctx = EdgeContext.build(batch["edge_index"], batch["z"].numel())
-            hint = int(ctx.column_hint(ctx.out_ptr, ctx.n_edges))
+            hint = int(ctx.column_hint(ctx.out_ptr, ctx.n_edges)[0])
             worst = max(float((tr_c[k] - tr_t[k]).abs().max() / tr_t[k].abs().max()) for k in tr_c
                         if isinstance(tr_c[k], torch.Tensor) and tr_c[k].dtype.is_floating_point)
             print(f"{name:30s} {prec:7s} hint {hint}  out rel diff {float((a - b).abs().max() / b.abs().max()):.2e}  "
