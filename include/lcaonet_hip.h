@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define LCAO_ABI_VERSION 1
+/* 2: lcao_build_csr gained err_flag and the coefficient kernels cst_row (round 2); the 16-bit coefficient kernels take
+ *    packed rows (lcao_lowp_pack_rows); the tile-queue workspace is 16 bytes, caller-zeroed once, persistent. */
+#define LCAO_ABI_VERSION 2
 
 #define LCAO_OK 0
 #define LCAO_ERR_INVALID (-1)     /* bad argument (null pointer, negative size, size over 2^31) */
@@ -36,6 +38,7 @@ extern "C" {
 enum { LCAO_ACT_NONE = 0, LCAO_ACT_SILU = 1, LCAO_ACT_SIGMOID = 2 };
 enum { LCAO_CUTOFF_ENVELOPE = 0, LCAO_CUTOFF_POLYNOMIAL = 1, LCAO_CUTOFF_COSINE = 2, LCAO_CUTOFF_NONE = 3 };
 enum { LCAO_RBF_HYDROGEN = 0, LCAO_RBF_BESSEL = 1 };
+enum { LCAO_PREC_BF16X3 = 0, LCAO_PREC_F16 = 1 };   /* the two precisions of the 16-bit matrix path (BASELINE config 3) */
 
 /* per-orbital row of the radial table handed to lcao_radial_basis: LCAO_ORB_STRIDE floats
  *   [0] zeta scale 2/(n*r0)   [1] normalisation C_nl   [2] l   [3] polynomial degree k=n-l-1
@@ -204,11 +207,20 @@ int lcao_pair_rows(const int64_t* z, const int32_t* src_p, const int32_t* dst_p,
 
 /* BASELINE config 3: the same fused kernel with both Dense layers on bf16 MFMA, every fp32 operand split into two
  * bf16 terms and each product run as three MFMAs with fp32 accumulation ("bf16x3": 6-9e-6 relative error on the MLP,
- * against 3.6e-3 for plain bf16).  No valence.  workspace >= 8 bytes, zero on first use (as above). */
-int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+ * against 3.6e-3 for plain bf16).  No valence.  workspace: as above (16 bytes, zero on first use).
+ * cst16: the coefficient rows PACKED by lcao_lowp_pack_rows (same row numbering as cst above: row order[p], or
+ * cst_row[p] of a table) — cst is the same tensor in every interaction (lcaonet.py:533-534), so its operands are
+ * prepared once per forward instead of once per (layer, edge, orbital).  n_orb <= 32. */
+int lcao_coeff_mlp_contract_bf16x3(const void* cst16, const float* rb, const int32_t* order, const int32_t* cst_row,
                                    const int32_t* l_of_d, const float* W1, const float* W2, const float* gate, const int32_t* src_p,
                                    int64_t n_edges, int n_orb, int C, int V, int n_l, float* A, float* B, float* Ag,
                                    float* gram, void* workspace, size_t ws_bytes, void* stream);
+
+/* MFMA operands of n_values fp32 numbers (n_values % 8 == 0; rows of C values, C % 32 == 0), per group of 8 values:
+ * LCAO_PREC_F16: 16 bytes, the values rounded to fp16;  LCAO_PREC_BF16X3: 32 bytes, 8 bf16 high terms then 8 bf16 low
+ * terms (x - hi).  out: device, lcao_lowp_packed_bytes(n_values, precision) bytes. */
+size_t lcao_lowp_packed_bytes(int64_t n_values, int precision);
+int lcao_lowp_pack_rows(const float* rows, int64_t n_values, int precision, void* out, void* stream);
 
 /* lcaonet.py:173-189 as one small fp32-MFMA GEMM per centre node (no LDS, no T-sized tensor):
  *   tbw[p,:] = sum_{q in In(s), q != p}  sum_l  Y_l(u_p.u_q) / max(sqrt(Y^T G_q Y), 1e-12) * Ag[q,l,:]
@@ -219,8 +231,8 @@ int lcao_triplet_gemm(const float* Ag, const float* gram, const float* uvec_p, c
 
 /* BASELINE config 3 at its STATED tolerance (1e-3): the same three fused kernels with operands rounded once to fp16 and ONE
  * v_mfma_f32_16x16x32_f16 per product (fp32 accumulation): ~3e-4 from fp32, where a single bf16 MFMA (3.6e-3 on the MLP
- * alone) does not meet the tolerance.  Same arguments as the _bf16x3 forms. */
-int lcao_coeff_mlp_contract_f16(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+ * alone) does not meet the tolerance.  Same arguments as the _bf16x3 forms (cst16 packed with LCAO_PREC_F16). */
+int lcao_coeff_mlp_contract_f16(const void* cst16, const float* rb, const int32_t* order, const int32_t* cst_row,
                                 const int32_t* l_of_d, const float* W1, const float* W2, const float* gate,
                                 const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, float* A, float* B,
                                 float* Ag, float* gram, void* workspace, size_t ws_bytes, void* stream);

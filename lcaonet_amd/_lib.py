@@ -44,6 +44,8 @@ SIGNATURES = {
     "lcao_coeff_mlp_contract": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, P, P, P, P, P, P, c_size_t, P],
     "lcao_coeff_mlp_contract_bf16x3": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, c_size_t, P],
     "lcao_coeff_mlp_contract_f16": [P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, c_size_t, P],
+    "lcao_lowp_packed_bytes": [L, I],
+    "lcao_lowp_pack_rows": [P, L, I, P, P],
     "lcao_edge_lcao_weight_f16": [P, P, P, P, L, I, P, P],
     "lcao_edge_node_message_f16": [P, P, P, P, P, P, P, L, I, P, P],
     "lcao_triplet_gemm": [P, P, P, P, P, P, L, L, I, I, P, P],
@@ -91,7 +93,8 @@ SIGNATURES = {
     "lcao_lds_bytes_coeff_mlp": [I, I, I],
     "lcao_debug_set_clock_probe": [P],
 }
-_RESTYPES = {"lcao_error_string": c_char_p, "lcao_lds_bytes_coeff_mlp": c_size_t,
+ABI_VERSION = 2
+_RESTYPES = {"lcao_error_string": c_char_p, "lcao_lds_bytes_coeff_mlp": c_size_t, "lcao_lowp_packed_bytes": c_size_t,
              "lcao_build_csr_workspace_bytes": c_size_t, "lcao_nl_workspace_bytes": c_size_t, "lcao_wgrad_workspace_bytes": c_size_t, "lcao_debug_set_clock_probe": None}
 
 _lib = None
@@ -115,8 +118,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
-    if lib.lcao_abi_version() != 1:
-        raise LcaoHipError(f"ABI version mismatch: library {lib.lcao_abi_version()}, binding 1")
+    if lib.lcao_abi_version() != ABI_VERSION:
+        raise LcaoHipError(f"ABI version mismatch: library {lib.lcao_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

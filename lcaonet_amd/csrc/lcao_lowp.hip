@@ -3,9 +3,22 @@
 //   PREC_BF16X3  every fp32 operand split into two bf16 terms, three MFMAs per product: ~1e-5 from fp32 (the fp32 bar)
 //   PREC_F16     operands rounded once to fp16 (11 significant bits), ONE MFMA per product: ~3e-4, inside config 3's
 //                stated tolerance of 1e-3, which a single bf16 MFMA (8 bits: 3.6e-3 on the MLP alone) does not meet
+#include <type_traits>
+
 #include "lcao_mfma.h"
 
 enum { PREC_BF16X3 = 0, PREC_F16 = 1 };
+
+// LDS prefetch distance of lowp_layer in steps (one fp16 fragment, or a hi/lo pair of bf16 fragments, per step)
+#ifndef LCAO_LOWP_PD_H
+#define LCAO_LOWP_PD_H 4
+#endif
+#ifndef LCAO_LOWP_PD_BF
+#define LCAO_LOWP_PD_BF 2
+#endif
+#ifndef LCAO_LOWP_THREADS
+#define LCAO_LOWP_THREADS 512
+#endif
 
 // ===================================================================================================
 // lcao_coeff_mlp_contract_bf16x3 / _f16 — BASELINE config 3 ("bf16 MFMA on the per-edge coeffs x hidden GEMM"):
@@ -38,15 +51,17 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8v& hi, bf16x8v
   }
 }
 
-// Weight planes in LDS: [plane][row][K + 8] 16-bit elements (272-B rows at K = 128: the 16 rows of a fragment hit 16
-// distinct 16-B slots).  PERMUTE stores the columns in the order a chained layer delivers its inputs (see header).
+// Weight planes in LDS, fragment-major: the 16 bytes a lane feeds to one MFMA (weight row rr, k-step s, lane group q) live
+// at element ((4 s + q) * rows + rr) * 8, so the 16 lanes of every ds_read_b128 service group (MI355X_MICROARCH.md, LDS
+// table) read 16 distinct 16-B slots: conflict-free, no padding.  Round 2's [row][K + 8] layout put (r, q + 1) and
+// (r + 1, q) into the same slot: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE (profiles/r03/k2_lowp_pmc_before.txt).
+// PERMUTE stores the columns in the order a chained layer delivers its inputs (see header).
 template <int PREC, bool PERMUTE>
 __device__ __forceinline__ void stage_weights_lowp(typename LowP<PREC>::T* __restrict__ planes, const float* __restrict__ W,
                                                    int rows, int K, float scale = 1.0f) {
   typedef typename LowP<PREC>::T T;
-  const int ld = K + 8;
   T* hi = planes;
-  T* lo = planes + rows * ld;
+  T* lo = planes + rows * K;
   for (int i = threadIdx.x; i < rows * K; i += blockDim.x) {
     const int rr = i / K, pos = i - rr * K;
     int col = pos;
@@ -56,144 +71,454 @@ __device__ __forceinline__ void stage_weights_lowp(typename LowP<PREC>::T* __res
     }
     const float w = W[(int64_t)rr * K + col] * scale;
     const T h = (T)w;
-    hi[rr * ld + pos] = h;
-    if (PREC == PREC_BF16X3) lo[rr * ld + pos] = (T)(w - (float)h);
+    const int dst = ((pos >> 3) * rows + rr) * 8 + (pos & 7);
+    hi[dst] = h;
+    if (PREC == PREC_BF16X3) lo[dst] = (T)(w - (float)h);
   }
 }
 
-// one Dense layer on a 16-row tile: out[m] += W[16m.., :] . in, input given as 8 floats per 32-wide k-step in B-operand order
+// the B operand of one 32-wide k-step: 8 values per lane, rounded once to fp16 or split into two bf16 terms
+template <int PREC> struct LowpOperand;
+template <> struct LowpOperand<PREC_F16> {
+  f16x8v hi;
+  __device__ __forceinline__ void set(const float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hi[j] = (_Float16)v[j];
+  }
+};
+template <> struct LowpOperand<PREC_BF16X3> {
+  bf16x8v hi, lo;
+  __device__ __forceinline__ void set(const float (&v)[8]) { split8(v, hi, lo); }
+};
+
+// one Dense layer on a 16-row tile: out[m] += W[16m.., :] . in, the input given as KS B operands (one per 32-wide k-step).
+// The (k-step, feature tile) sequence is flattened and the weight fragment of step t + PD is requested from LDS before the
+// MFMA(s) of step t issue (counted lgkmcnt waits): a 16-cycle v_mfma_f32_16x16x32 covers none of a ds_read_b128's latency.
 template <int PREC, int KS, int MT>
-__device__ __forceinline__ void lowp_layer(const typename LowP<PREC>::T* __restrict__ planes, int rows, int ld, int r, int q,
-                                           const float (&in)[KS][8], f32x4v (&out)[MT]) {
+__device__ __forceinline__ void lowp_layer(const typename LowP<PREC>::T* __restrict__ planes, int rows, int K, int r, int q,
+                                           const LowpOperand<PREC> (&in)[KS], f32x4v (&out)[MT]) {
+  constexpr int STEPS = KS * MT;
+  const int fs = 4 * rows * 8;   // elements between the fragments of consecutive k-steps
   if constexpr (PREC == PREC_BF16X3) {
-    const __bf16* wh = planes;
-    const __bf16* wl = planes + rows * ld;
+    constexpr int PD = LCAO_LOWP_PD_BF < STEPS ? LCAO_LOWP_PD_BF : STEPS;
+    const __bf16* wh = planes + (q * rows + r) * 8;
+    const __bf16* wl = wh + rows * K;
+    bf16x8v fh[STEPS], fl[STEPS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      bf16x8v xh, xl;
-      split8(in[s], xh, xl);
+    for (int t = 0; t < PD; ++t) {
+      fh[t] = *(const bf16x8v*)(wh + (t / MT) * fs + 128 * (t % MT));
+      fl[t] = *(const bf16x8v*)(wl + (t / MT) * fs + 128 * (t % MT));
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const bf16x8v a_h = *(const bf16x8v*)(wh + (16 * m + r) * ld + 32 * s + 8 * q);
-        const bf16x8v a_l = *(const bf16x8v*)(wl + (16 * m + r) * ld + 32 * s + 8 * q);
-        out[m] = MFMA16BF(a_h, xl, out[m]);
-        out[m] = MFMA16BF(a_l, xh, out[m]);
-        out[m] = MFMA16BF(a_h, xh, out[m]);
+    for (int t = 0; t < STEPS; ++t) {
+      const int s = t / MT, m = t % MT;
+      if (t + PD < STEPS) {
+        const int t2 = t + PD;
+        fh[t2] = *(const bf16x8v*)(wh + (t2 / MT) * fs + 128 * (t2 % MT));
+        fl[t2] = *(const bf16x8v*)(wl + (t2 / MT) * fs + 128 * (t2 % MT));
       }
+      out[m] = MFMA16BF(fh[t], in[s].lo, out[m]);
+      out[m] = MFMA16BF(fl[t], in[s].hi, out[m]);
+      out[m] = MFMA16BF(fh[t], in[s].hi, out[m]);
+      if (t + PD < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     }
   } else {
+    constexpr int PD = LCAO_LOWP_PD_H < STEPS ? LCAO_LOWP_PD_H : STEPS;
+    const _Float16* w0 = planes + (q * rows + r) * 8;
+    f16x8v fr[STEPS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      f16x8v xh;
+    for (int t = 0; t < PD; ++t) fr[t] = *(const f16x8v*)(w0 + (t / MT) * fs + 128 * (t % MT));
+    __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xh[j] = (_Float16)in[s][j];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const f16x8v a_h = *(const f16x8v*)(planes + (16 * m + r) * ld + 32 * s + 8 * q);
-        out[m] = MFMA16H(a_h, xh, out[m]);
-      }
+    for (int t = 0; t < STEPS; ++t) {
+      const int s = t / MT, m = t % MT;
+      if (t + PD < STEPS && !((LCAO_ABL & 4) && t + PD >= 2 * PD))
+        fr[t + PD] = *(const f16x8v*)(w0 + ((t + PD) / MT) * fs + 128 * ((t + PD) % MT));
+      out[m] = MFMA16H(fr[(LCAO_ABL & 4) ? t % (2 * PD) : t], in[s].hi, out[m]);
+      if (t + PD < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
   }
 }
 
-template <int PREC, int C, int V, int NL, int THREADS>
+// ---------------------------------------------------------------------------------------------------
+// Packed coefficient rows: the B operands of layer 1, prepared once per forward instead of once per (layer, edge, orbital)
+// — cst is the same tensor in every interaction (lcaonet.py:533-534).  Per group of 8 consecutive values:
+//   f16     16 bytes: the 8 values rounded to fp16
+//   bf16x3  32 bytes: 8 bf16 high terms, then 8 bf16 low terms (x - float(hi))
+// so a lane reads the operand of one k-step with one (two) 16-byte load(s) and issues no conversion.
+// ---------------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ void k_lowp_pack_rows(const float* __restrict__ rows, int64_t n_groups, unsigned char* __restrict__ out) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4v a = *(const f32x4v*)(rows + 8 * g), b = *(const f32x4v*)(rows + 8 * g + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (PREC == PREC_F16) {
+      f16x8v h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+      *(f16x8v*)(out + 16 * g) = h;
+    } else {
+      bf16x8v hi, lo;
+      split8(v, hi, lo);
+      *(bf16x8v*)(out + 32 * g) = hi;
+      *(bf16x8v*)(out + 32 * g + 16) = lo;
+    }
+  }
+}
+
+extern "C" size_t lcao_lowp_packed_bytes(int64_t n_values, int precision) {
+  return (size_t)(n_values / 8) * (precision == LCAO_PREC_F16 ? 16 : 32);
+}
+
+extern "C" int lcao_lowp_pack_rows(const float* rows, int64_t n_values, int precision, void* out, void* stream) {
+  if (n_values < 0 || n_values % 8 || (precision != LCAO_PREC_F16 && precision != LCAO_PREC_BF16X3)) return LCAO_ERR_INVALID;
+  if (n_values == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(rows); LCAO_CHECK_PTR(out);
+  const int64_t groups = n_values / 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == LCAO_PREC_F16)
+    hipLaunchKernelGGL(k_lowp_pack_rows<PREC_F16>, dim3(lcao_blocks(groups, 256, 8192)), dim3(256), 0, st, rows, groups,
+                       (unsigned char*)out);
+  else
+    hipLaunchKernelGGL(k_lowp_pack_rows<PREC_BF16X3>, dim3(lcao_blocks(groups, 256, 8192)), dim3(256), 0, st, rows, groups,
+                       (unsigned char*)out);
+  return lcao_launch_status();
+}
+
+// the operand of k-step s (values 32 s + 8 q ..) of a packed row
+template <int PREC>
+__device__ __forceinline__ void load_packed(LowpOperand<PREC>& op, const unsigned char* __restrict__ row, int s, int q) {
+  if constexpr (PREC == PREC_F16) {
+    op.hi = *(const f16x8v*)(row + 16 * (4 * s + q));
+  } else {
+    op.hi = *(const bf16x8v*)(row + 32 * (4 * s + q));
+    op.lo = *(const bf16x8v*)(row + 32 * (4 * s + q) + 16);
+  }
+}
+
+// Diagnostic build (-DLCAO_LOWP_CLK, tools/k2_lowp_time.py; never in the shipped library): per-wave cycle totals of the
+// kernel's phases and the in-kernel clock (s_memtime / s_memrealtime), written to a buffer no kernel reads.
+#ifdef LCAO_LOWP_CLK
+static unsigned long long* g_lowp_clk = nullptr;
+extern "C" void lcao_debug_set_lowp_clock(void* buf) { g_lowp_clk = (unsigned long long*)buf; }
+#define LOWP_STAMP(i)                                                  \
+  do {                                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+    ph[i] += t_ - tl;                                                  \
+    tl = t_;                                                           \
+  } while (0)
+#define LOWP_CLK_ARG , unsigned long long* __restrict__ clk
+#define LOWP_CLK_PASS , g_lowp_clk
+#else
+#define LOWP_STAMP(i)
+#define LOWP_CLK_ARG
+#define LOWP_CLK_PASS
+#endif
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// g(x') = x' / (1 + 2^(-x')) on a pair (lcao_mfma.h) in three stages that the weaving below issues in DIFFERENT steps, so
+// no instruction waits on the transcendental before it:  a: two v_exp_f32   b: v_pk_add_f32, two v_rcp_f32   c: v_pk_mul_f32
+__device__ __forceinline__ f32x2v lowp_act_a(f32x2v x) {
+  return f32x2v{__builtin_amdgcn_exp2f(-x[0]), __builtin_amdgcn_exp2f(-x[1])};
+}
+__device__ __forceinline__ f32x2v lowp_act_b(f32x2v e) {
+  e = e + 1.0f;
+  return f32x2v{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
+__device__ __forceinline__ f32x2v lowp_act_c(f32x2v x, f32x2v rcp) {
+#if LCAO_ABL & 1
+  return x;
+#else
+  return x * rcp;
+#endif
+}
+__device__ __forceinline__ f32x2v lowp_act2(f32x2v x) { return lowp_act_c(x, lowp_act_b(lowp_act_a(x))); }
+
+// One Dense layer of the coefficient kernel with a second, independent instruction stream woven in: after the MFMA(s) of
+// every (k-step, feature tile) step t, `valu(t)` emits a slice of VALU / transcendental work that does not depend on this
+// layer's accumulators (activations of the OTHER layer), and a full scheduling fence pins the order, so the wave's own
+// stream alternates matrix and vector instructions.  On gfx950 a wave's VALU stream and its SIMD partner's
+// v_mfma_f32_16x16x32 stream overlap (profiles/r03/mfma16_valu_overlap.txt: both = max), but only while the two waves are
+// in different phases; with the streams mixed inside each wave every issue slot has work of both kinds whatever the
+// partner does.  (sched_group_barrier pipelines over blocks of this size were not honoured: the activations were
+// emitted in runs ahead of the MFMAs.)
+template <int PREC, int KS, int MT, typename InFn, typename ValuFn>
+__device__ __forceinline__ void lowp_layer_mix(const typename LowP<PREC>::T* __restrict__ planes, int rows, int K, int r, int q,
+                                               InFn in, f32x4v (&out)[MT], ValuFn valu) {
+  constexpr int STEPS = KS * MT;
+  const int fs = 4 * rows * 8;   // elements between the fragments of consecutive k-steps
+  constexpr int PD0 = PREC == PREC_BF16X3 ? LCAO_LOWP_PD_BF : LCAO_LOWP_PD_H;
+  constexpr int PD = PD0 < STEPS ? PD0 : STEPS;
+  typedef typename LowP<PREC>::T T;
+  typedef T t8 __attribute__((ext_vector_type(8)));
+  const T* wh = planes + (q * rows + r) * 8;
+  const T* wl = wh + rows * K;
+  t8 fh[STEPS], fl[PREC == PREC_BF16X3 ? STEPS : 1];
+#pragma unroll
+  for (int t = 0; t < PD; ++t) {
+    fh[t] = *(const t8*)(wh + (t / MT) * fs + 128 * (t % MT));
+    if constexpr (PREC == PREC_BF16X3) fl[t] = *(const t8*)(wl + (t / MT) * fs + 128 * (t % MT));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) {
+    const int s = t / MT, m = t % MT;
+    if (t + PD < STEPS && !((LCAO_ABL & 4) && t + PD >= 2 * PD)) {
+      const int t2 = t + PD;
+      fh[t2] = *(const t8*)(wh + (t2 / MT) * fs + 128 * (t2 % MT));
+      if constexpr (PREC == PREC_BF16X3) fl[t2] = *(const t8*)(wl + (t2 / MT) * fs + 128 * (t2 % MT));
+    }
+    const LowpOperand<PREC>& b = in(s);
+    const int tf = (LCAO_ABL & 4) ? t % (2 * PD) : t;   // ablation: fragments read once per layer call
+    if constexpr (PREC == PREC_BF16X3) {
+      out[m] = MFMA16BF(fh[tf], b.lo, out[m]);
+      out[m] = MFMA16BF(fl[tf], b.hi, out[m]);
+      out[m] = MFMA16BF(fh[tf], b.hi, out[m]);
+    } else {
+      out[m] = MFMA16H(fh[tf], b.hi, out[m]);
+    }
+    valu(t);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ===================================================================================================
+// The persistent coefficient kernel (BASELINE config 3).  Round-3 structure (round 2: waves spent 55 % of their cycles in
+// s_waitcnt and the two waves of a SIMD ran the same phase at the same time; profiles/r03/k2_lowp_*.txt):
+//   * orbitals are walked grouped by l (a permutation built once per workgroup), so the running accumulator `cur` is one
+//     register set and the per-l sums are parked when a group ends — the step body has no branch;
+//   * every step is two blocks, each a mix of one layer's MFMAs with the other layer's activations:
+//       Y(u): layer 2 of orbital u   woven with  SiLU(layer-1 output of u)        (k-step s + 1 under the MFMAs of k-step s)
+//       X(u): layer 1 of the NEXT orbital (of the next tile after a tile's last)  woven with  cur += w SiLU(layer-2 output of u)
+//   * the rows of the next orbital are packed 16-bit operands (lcao_lowp_pack_rows), requested at the top of Y(u) and
+//     consumed in X(u): straight-line code, so the wait is a counted vmcnt behind younger loads only;
+//   * the next tile is drawn from the queue at the top of the current one; its index words are read two orbitals before
+//     the end; stores are unconditional (lanes past the last edge recompute and rewrite edge E - 1 bit for bit).
+// ===================================================================================================
+template <int PREC, int C, int V, int NL, int THREADS, bool GATED>
 __global__ __launch_bounds__(THREADS) void k_coeff_mlp_lowp(
-    const float* __restrict__ cst, const float* __restrict__ rb, const int32_t* __restrict__ order,
+    const unsigned char* __restrict__ cst16, const float* __restrict__ rb, const int32_t* __restrict__ order,
     const int32_t* __restrict__ cst_row, const int32_t* __restrict__ l_of_d, const float* __restrict__ W1,
     const float* __restrict__ W2, int64_t E, int D, float* __restrict__ A, float* __restrict__ Bout,
     const float* __restrict__ gate, const int32_t* __restrict__ src_p, float* __restrict__ Ag, float* __restrict__ gram,
-    unsigned* __restrict__ tile_counter) {
+    unsigned* __restrict__ tile_counter LOWP_CLK_ARG) {
   static_assert(C % 32 == 0 && V % 32 == 0, "k-steps are 32 wide");
   typedef typename LowP<PREC>::T T;
-  constexpr int KS1 = C / 32, KS2 = V / 32, MT = V / 16, LD1 = C + 8, LD2 = V + 8, WAVES = THREADS / 64;
+  constexpr int KS1 = C / 32, KS2 = V / 32, MT = V / 16, WAVES = THREADS / 64;
   constexpr int NP = LowP<PREC>::PLANES;
+  constexpr int ROW_BYTES = C * 2 * NP;   // one packed (edge, orbital) row
   extern __shared__ unsigned char lds_raw[];
   T* w1p = (T*)lds_raw;
-  T* w2p = w1p + NP * V * LD1;
+  T* w2p = w1p + NP * V * C;
+#ifdef LCAO_LOWP_CLK
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl = t_start;
+#endif
   // log2(e) folded into the first layer (lcao_mfma.h: g(x') = SiLU(x) log2 e for x' = x log2 e, so the second layer's
   // input and output carry the factor and it leaves through the radial multiplier): one VALU multiply less per activation
   stage_weights_lowp<PREC, false>(w1p, W1, V, C, LCAO_LOG2E);
   stage_weights_lowp<PREC, true>(w2p, W2, V, V);
   __syncthreads();
+  LOWP_STAMP(0);   // staging
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int64_t n_tiles = (E + 15) >> 4;
-  const int64_t first_dynamic = (int64_t)gridDim.x * WAVES;
-  int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
-  for (; tile < n_tiles;) {
-    const int64_t p = tile * 16 + r;
-    const bool valid = p < E;
-    const int64_t pc = valid ? p : E - 1;
-    const int64_t e = order ? order[pc] : pc;
-    const int64_t ec = cst_row ? (int64_t)cst_row[pc] : e;   // gathered coefficient rows (see k_coeff_mlp)
-    const float* xrow = cst + ec * (int64_t)D * C + 8 * q;
-    const float* rbrow = rb + e * D;
+  // orbitals are walked grouped by l: lmask[l] = the orbitals d with l_of_d[d] == l (scalar registers; D <= 32)
+  unsigned lmask[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) lmask[l] = 0u;
+  for (int d = 0; d < D; ++d) {
+    const int l = l_of_d[d];
+#pragma unroll
+    for (int ll = 0; ll < NL; ++ll) lmask[ll] |= (l == ll ? 1u : 0u) << d;
+  }
+  unsigned first_mask = 0u;   // the group the walk starts with
+#pragma unroll
+  for (int l = NL - 1; l >= 0; --l) first_mask = lmask[l] ? lmask[l] : first_mask;
+  const int d_first = first_mask ? __builtin_ctz(first_mask) : 0;
+  unsigned all_mask = 0u;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) all_mask |= lmask[l];
+  const int n_steps = __builtin_popcount(all_mask);   // = D for a valid l_of_d
+  const int n_tiles = (int)((E + 15) >> 4);
+  const int first_dynamic = (int)gridDim.x * WAVES;
+  int tile = (int)blockIdx.x * WAVES + wave;
+
+  // a tile's per-lane inputs as 32-bit row numbers (E < 2^31: checked by the host)
+  struct Rows { int pc, e, ec, src; };
+  auto tile_inputs = [&](int t) {
+    Rows n;
+    const int p = t * 16 + r;
+    n.pc = p < (int)E ? p : (int)E - 1;
+    n.e = order ? order[n.pc] : n.pc;
+    n.ec = cst_row ? cst_row[n.pc] : n.e;   // gathered coefficient rows (see k_coeff_mlp)
+    n.src = GATED ? src_p[n.pc] : 0;
+    return n;
+  };
+  LowpOperand<PREC> x[KS1];
+  auto load_rows = [&](const Rows& n, int d) {
+    const unsigned char* row = cst16 + ((int64_t)n.ec * D + d) * ROW_BYTES;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) load_packed<PREC>(x[s], row, s, q);
+  };
+  f32x4v h[MT], o[MT];
+  auto zero = [](f32x4v (&v)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) v[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  };
+  auto x_of = [&](int s) -> const LowpOperand<PREC>& { return x[s]; };
+
+  Rows nx = {0, 0, 0, 0};
+  float w_next = 0.f;
+  if (tile < n_tiles) {
+    nx = tile_inputs(tile);
+    w_next = rb[(int64_t)nx.e * D + d_first];
+    load_rows(nx, d_first);
+    zero(h);
+    lowp_layer_mix<PREC, KS1, MT>(w1p, V, C, r, q, x_of, h, [](int) {});
+  }
+  while (tile < n_tiles) {
+    unsigned drawn = 0;
+    if (lane == 0) drawn = atomicAdd(tile_counter, 1u);   // consumed two steps before the tile ends
+    int tile_n = n_tiles;
+    const Rows cur_rows = nx;
     f32x4v acc[NL][MT];
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[l][m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    f32x4v x[KS1][2];
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) {
-      x[s][0] = *(const f32x4v*)(xrow + 32 * s);
-      x[s][1] = *(const f32x4v*)(xrow + 32 * s + 4);
-    }
-    for (int d = 0; d < D; ++d) {
+    for (int l = 0; l < NL; ++l) zero(acc[l]);
+    int left = n_steps;   // steps of this tile still to run, this one included
+    f32x4v gt[GATED ? MT : 1];
+    // one step: orbital (group L) whose layer-1 output is in h; dn = the orbital that follows in this tile, or -1
+    auto step = [&](auto lc, int dn) {
+      constexpr int L = decltype(lc)::value;
       asm volatile("" ::: "memory");  // the LDS fragments are loop-invariant: keep them from being hoisted (spills)
-      f32x4v h[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) h[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      float xin[KS1][8];
-#pragma unroll
-      for (int s = 0; s < KS1; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          xin[s][j] = x[s][0][j];
-          xin[s][4 + j] = x[s][1][j];
-        }
-      lowp_layer<PREC, KS1, MT>(w1p, V, LD1, r, q, xin, h);
-      if (d + 1 < D) {
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-          x[s][0] = *(const f32x4v*)(xrow + (d + 1) * C + 32 * s);
-          x[s][1] = *(const f32x4v*)(xrow + (d + 1) * C + 32 * s + 4);
-        }
+      const float w = w_next * LCAO_INV_LOG2E;
+      if (left == (n_steps >= 2 ? 2 : 1)) {
+        tile_n = first_dynamic + (int)__builtin_amdgcn_readfirstlane(drawn);
+        if (tile_n < n_tiles) nx = tile_inputs(tile_n);
       }
-      float hin[KS2][8];
+      LOWP_STAMP(1);   // step top / next tile's index words
+      // ---- Y: rows + radial weight of the next step requested, then layer 2 woven with the first activation
+      if (dn >= 0) {
+        w_next = rb[(int64_t)cur_rows.e * D + dn];
+        load_rows(cur_rows, dn);
+      } else if (tile_n < n_tiles) {
+        w_next = rb[(int64_t)nx.e * D + d_first];
+        load_rows(nx, d_first);
+      }
+      // layer 2 runs k-step by k-step on hin[s] = SiLU of feature tiles 2s, 2s + 1 of layer 1; the activations of k-step
+      // s + 1 are issued pair by pair between the MFMAs of k-step s
+      LowpOperand<PREC> hin[KS2];
+      float av[8];
+      auto h_pair = [&](int s, int pr) {   // values 2 pr, 2 pr + 1 of the 8 this lane feeds to k-step s
+        const int tl_ = 2 * s + (pr >> 1), j = 2 * (pr & 1);
+        return f32x2v{h[tl_][j], h[tl_][j + 1]};
+      };
 #pragma unroll
-      for (int s = 0; s < KS2; ++s)
+      for (int pr = 0; pr < 4; ++pr) {
+        const f32x2v y = lowp_act2(h_pair(0, pr));
+        av[2 * pr] = y[0];
+        av[2 * pr + 1] = y[1];
+      }
+      hin[0].set(av);
+      zero(o);
+      f32x2v ya[4], yb[4];   // stage results of the four pairs of the k-step being prepared
+      lowp_layer_mix<PREC, KS2, MT>(
+          w2p, V, V, r, q, [&](int s) -> const LowpOperand<PREC>& { return hin[s]; }, o, [&](int t) {
+            const int s = t / MT, m = t % MT;
+            if (s + 1 >= KS2) return;
+            // pair pr: stage a after step 2 pr' , b after the next, c after the one after (MT = 8; fewer steps: stages share)
+            constexpr int SPP = MT >= 8 ? 2 : 1;   // steps per pair
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          hin[s][j] = lcao_silu_log2e(h[2 * s][j]);
-          hin[s][4 + j] = lcao_silu_log2e(h[2 * s + 1][j]);
+            for (int pr = 0; pr < 4; ++pr) {
+              const int ta = (pr * SPP * MT) / (4 * SPP), tb = ta + 1, tc = ta + 2;
+              if (MT >= 8) {
+                if (m == ta) ya[pr] = lowp_act_a(h_pair(s + 1, pr));
+                if (m == tb) yb[pr] = lowp_act_b(ya[pr]);
+                if (m == (tc < MT ? tc : MT - 1)) {
+                  const f32x2v y = lowp_act_c(h_pair(s + 1, pr), yb[pr]);
+                  av[2 * pr] = y[0];
+                  av[2 * pr + 1] = y[1];
+                }
+              } else if (pr * MT / 4 == m) {
+                const f32x2v y = lowp_act2(h_pair(s + 1, pr));
+                av[2 * pr] = y[0];
+                av[2 * pr + 1] = y[1];
+              }
+            }
+            if (m == MT - 1) hin[s + 1].set(av);
+          });
+      LOWP_STAMP(2);   // Y: layer 2 + activation 1
+      // ---- X: layer 1 of the next step woven with the second activation and the accumulation into this group's sum
+      zero(h);
+      const f32x2v w2 = {w, w};
+      constexpr int STEPS1 = KS1 * MT, NPR = 2 * MT;   // pair pr: stages after steps pr STEPS1 / NPR + {0, 1, 2}
+      f32x2v za[NPR], zb[NPR];
+      auto o_pair = [&](int pr) { return f32x2v{o[pr >> 1][2 * (pr & 1)], o[pr >> 1][2 * (pr & 1) + 1]}; };
+      auto finish = [&](int pr, f32x2v y) {
+        const int m = pr >> 1, j = 2 * (pr & 1);
+        const f32x2v c2 = f32x2v{acc[L][m][j], acc[L][m][j + 1]} + w2 * y;
+        acc[L][m][j] = c2[0];
+        acc[L][m][j + 1] = c2[1];
+      };
+      lowp_layer_mix<PREC, KS1, MT>(w1p, V, C, r, q, x_of, h, [&](int t) {
+#pragma unroll
+        for (int pr = 0; pr < NPR; ++pr) {
+          const int ta = pr * STEPS1 / NPR;
+          if (STEPS1 >= 2 * NPR) {
+            const int tc = ta + 2 < STEPS1 ? ta + 2 : STEPS1 - 1;
+            if (t == ta) za[pr] = lowp_act_a(o_pair(pr));
+            if (t == ta + 1) zb[pr] = lowp_act_b(za[pr]);
+            if (t == tc) finish(pr, lowp_act_c(o_pair(pr), zb[pr]));
+          } else if (t == ta) {
+            finish(pr, lowp_act2(o_pair(pr)));
+          }
         }
-      f32x4v o[MT];
+      });
+      LOWP_STAMP(3);   // X: layer 1 + activation 2
+      if (GATED && dn < 0) {
+        // the centre's gate row for the epilogue, requested here (another basic block) so that B and the Gram matrix are
+        // computed while it is in flight: within the epilogue hipcc sinks the loads to their first use
 #pragma unroll
-      for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      lowp_layer<PREC, KS2, MT>(w2p, V, LD2, r, q, hin, o);
-      const float w = rbrow[d] * LCAO_INV_LOG2E;
-      const int l = l_of_d[d];
+        for (int m = 0; m < MT; ++m) gt[m] = *(const f32x4v*)(gate + (int64_t)cur_rows.src * V + 16 * m + 4 * q);
+      }
+      --left;
+    };
+    auto group = [&](auto lc) {
+      constexpr int L = decltype(lc)::value;
+      unsigned later = 0u;   // the next non-empty group after L
 #pragma unroll
-      for (int ll = 0; ll < NL; ++ll) {
-        if (l == ll) {
+      for (int l = NL - 1; l > L; --l) later = lmask[l] ? lmask[l] : later;
+      unsigned rem = lmask[L];
+      while (rem) {
+        rem &= rem - 1;   // the step's own orbital: its rows and weight were requested one step earlier
+        const int dn = rem ? __builtin_ctz(rem) : (later ? __builtin_ctz(later) : -1);
+        step(lc, dn);
+      }
+    };
+    group(std::integral_constant<int, 0>{});
+    if constexpr (NL > 1) group(std::integral_constant<int, 1>{});
+    if constexpr (NL > 2) group(std::integral_constant<int, 2>{});
+    if constexpr (NL > 3) group(std::integral_constant<int, 3>{});
+    // epilogue: B, Gram of the ungated A, gated copy or raw A (as k_coeff_mlp)
+    if (!((LCAO_ABL & 32) && acc[0][0][0] != 12345.f)) {
+      float* Bp = Bout + (int64_t)cur_rows.pc * V + 4 * q;
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[ll][m] += w * lcao_silu_log2e4(o[m]);
-        }
+      for (int m = 0; m < MT; ++m) {
+        f32x4v bsum = acc[0][m];
+#pragma unroll
+        for (int l = 1; l < NL; ++l) bsum += acc[l][m];
+        *(f32x4v*)(Bp + 16 * m) = bsum;
       }
     }
-    // epilogue: identical to k_coeff_mlp (B, Gram of the ungated A, gated copy or raw A)
-    f32x4v bsum[MT];
+    LOWP_STAMP(7);   // gate request + B
+    if (GATED) {
+      float g[12];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      bsum[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int l = 0; l < NL; ++l) bsum[m] += acc[l][m];
-    }
-    if (gram) {
-      float g[10];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) g[i] = 0.f;
+      for (int i = 0; i < 12; ++i) g[i] = 0.f;
       int gi = 0;
 #pragma unroll
       for (int l = 0; l < 4; ++l)
@@ -211,78 +536,89 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_lowp(
           }
           ++gi;
         }
-      if (valid && q == 0) {
-        float* gp = gram + p * 10;
+      g[10] = g[9];   // lane group q stores entries q, q + 4, q + 8 (entries 10, 11 repeat entry 9): three stores, no branch
+      g[11] = g[9];
+      float* gp = gram + (int64_t)cur_rows.pc * 10;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) gp[i] = g[i];
+      for (int k = 0; k < 3; ++k) {
+        const float v = q == 0 ? g[4 * k] : (q == 1 ? g[4 * k + 1] : (q == 2 ? g[4 * k + 2] : g[4 * k + 3]));
+        const int i = 4 * k + q;
+        gp[i < 10 ? i : 9] = v;
       }
     }
-    if (valid) {
-      float* Bp = Bout + p * (int64_t)V + 4 * q;
+    LOWP_STAMP(8);   // Gram
+    if (!((LCAO_ABL & 32) && acc[0][0][0] != 12345.f)) {
+      float* Ap = (GATED ? Ag : A) + (int64_t)cur_rows.pc * NL * V + 4 * q;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        *(f32x4v*)(Bp + 16 * m) = bsum[m];
-        if (Ag) {
-          const f32x4v gt = *(const f32x4v*)(gate + (int64_t)src_p[p] * V + 16 * m + 4 * q);
-          float* Agp = Ag + p * (int64_t)NL * V + 4 * q;
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int l = 0; l < NL; ++l) *(f32x4v*)(Agp + l * V + 16 * m) = acc[l][m] * gt;
-        } else {
-          float* Ap = A + p * (int64_t)NL * V + 4 * q;
-#pragma unroll
-          for (int l = 0; l < NL; ++l) *(f32x4v*)(Ap + l * V + 16 * m) = acc[l][m];
-        }
-      }
+        for (int l = 0; l < NL; ++l) *(f32x4v*)(Ap + l * V + 16 * m) = GATED ? acc[l][m] * gt[m] : acc[l][m];
     }
-    unsigned nxt = 0;
-    if (lane == 0) nxt = atomicAdd(tile_counter, 1u);
-    tile = first_dynamic + (int64_t)__builtin_amdgcn_readfirstlane(nxt);
+    LOWP_STAMP(6);   // A stores
+    tile = tile_n;
   }
+#ifdef LCAO_LOWP_CLK
+  if (clk && lane == 0) {
+    unsigned long long* o_ = clk + 13 * ((size_t)blockIdx.x * WAVES + wave);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) o_[i] = ph[i];
+    o_[10] = __builtin_amdgcn_s_memtime() - t_start;
+    o_[11] = __builtin_amdgcn_s_memrealtime() - r_start;
+    o_[12] = r_start;
+  }
+#endif
   if (lane == 0) lcao_tile_queue_leave(tile_counter, gridDim.x * (THREADS / 64));   // the last wave re-arms the queue
 }
 
+// 512 threads (two waves per SIMD share the LDS weights) while the accumulators fit 256 VGPRs (n_l <= 3 at V = 128)
 template <int PREC, int C, int V, int NL>
-static int launch_coeff_mlp_lowp(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+static int launch_coeff_mlp_lowp(const void* cst16, const float* rb, const int32_t* order, const int32_t* cst_row,
                                  const int32_t* l_of_d, const float* W1, const float* W2, int64_t E, int D, float* A,
                                  float* Bout, const float* gate, const int32_t* src_p, float* Ag, float* gram,
                                  unsigned* counter, hipStream_t st) {
-  constexpr int THREADS = 512;
+  constexpr int THREADS = (NL * V > 384) ? 256 : LCAO_LOWP_THREADS;
   constexpr int NP = LowP<PREC>::PLANES;
-  size_t lds = (size_t(NP) * V * (C + 8) + size_t(NP) * V * (V + 8)) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_coeff_mlp_lowp<PREC, C, V, NL, THREADS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return int(e);
-    attr_set = true;
-  }
+  const size_t lds = (size_t(NP) * V * C + size_t(NP) * V * V) * 2;
   constexpr int WAVES = THREADS / 64;
   int64_t tiles = (E + 15) / 16;
   int64_t groups = (tiles + WAVES - 1) / WAVES;
   int64_t cap = (int64_t)lcao_num_cu() * ((lds > 80 * 1024) ? 1 : 2);
   if (groups > cap) groups = cap;
-  hipLaunchKernelGGL((k_coeff_mlp_lowp<PREC, C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb,
-                     order, cst_row, l_of_d, W1, W2, E, D, A, Bout, gate, src_p, Ag, gram, counter);
+  const unsigned char* c16 = (const unsigned char*)cst16;
+  if (Ag) {
+    static bool done = false;
+    int rc = set_lds_attr(k_coeff_mlp_lowp<PREC, C, V, NL, THREADS, true>, lds, done);
+    if (rc != LCAO_OK) return rc;
+    hipLaunchKernelGGL((k_coeff_mlp_lowp<PREC, C, V, NL, THREADS, true>), dim3((unsigned)groups), dim3(THREADS), lds, st, c16,
+                       rb, order, cst_row, l_of_d, W1, W2, E, D, A, Bout, gate, src_p, Ag, gram, counter LOWP_CLK_PASS);
+  } else {
+    static bool done = false;
+    int rc = set_lds_attr(k_coeff_mlp_lowp<PREC, C, V, NL, THREADS, false>, lds, done);
+    if (rc != LCAO_OK) return rc;
+    hipLaunchKernelGGL((k_coeff_mlp_lowp<PREC, C, V, NL, THREADS, false>), dim3((unsigned)groups), dim3(THREADS), lds, st, c16,
+                       rb, order, cst_row, l_of_d, W1, W2, E, D, A, Bout, gate, src_p, Ag, gram, counter LOWP_CLK_PASS);
+  }
   return lcao_launch_status();
 }
 
 template <int PREC>
-static int coeff_mlp_contract_lowp(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+static int coeff_mlp_contract_lowp(const void* cst16, const float* rb, const int32_t* order, const int32_t* cst_row,
                                    const int32_t* l_of_d, const float* W1, const float* W2, const float* gate,
                                    const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, float* A, float* B,
                                    float* Ag, float* gram, void* workspace, size_t ws_bytes, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   if (n_orb <= 0 || C <= 0 || V <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
-  LCAO_CHECK_PTR(cst); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(W1); LCAO_CHECK_PTR(W2);
+  LCAO_CHECK_PTR(cst16); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(W1); LCAO_CHECK_PTR(W2);
   LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(workspace);
   if (Ag) { LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(gram); } else { LCAO_CHECK_PTR(A); }
   if (ws_bytes < 2 * sizeof(unsigned)) return LCAO_ERR_INVALID;   // {drawn, left} of the tile queue
+  if (n_orb > 32) return LCAO_ERR_UNSUPPORTED;                    // the orbitals of each l are a 32-bit mask
   hipStream_t st = (hipStream_t)stream;
   unsigned* ctr = (unsigned*)workspace;
 #define LP_CASE(C_, V_, NL_)                                                                                       \
   if (C == C_ && V == V_ && n_l == NL_)                                                                            \
-    return launch_coeff_mlp_lowp<PREC, C_, V_, NL_>(cst, rb, order, cst_row, l_of_d, W1, W2, n_edges, n_orb, A, B, gate, \
+    return launch_coeff_mlp_lowp<PREC, C_, V_, NL_>(cst16, rb, order, cst_row, l_of_d, W1, W2, n_edges, n_orb, A, B, gate, \
                                                     src_p, Ag, Ag ? gram : nullptr, ctr, st);
 #define LP_CV(C_, V_) LP_CASE(C_, V_, 1) LP_CASE(C_, V_, 2) LP_CASE(C_, V_, 3) LP_CASE(C_, V_, 4)
   LP_CV(128, 128) LP_CV(64, 64) LP_CV(32, 32)
@@ -291,20 +627,20 @@ static int coeff_mlp_contract_lowp(const float* cst, const float* rb, const int3
   return LCAO_ERR_UNSUPPORTED;
 }
 
-extern "C" int lcao_coeff_mlp_contract_bf16x3(const float* cst, const float* rb, const int32_t* order,
+extern "C" int lcao_coeff_mlp_contract_bf16x3(const void* cst16, const float* rb, const int32_t* order,
                                               const int32_t* cst_row, const int32_t* l_of_d, const float* W1, const float* W2,
                                               const float* gate, const int32_t* src_p, int64_t n_edges, int n_orb, int C,
                                               int V, int n_l, float* A, float* B, float* Ag, float* gram,
                                               void* workspace, size_t ws_bytes, void* stream) {
-  return coeff_mlp_contract_lowp<PREC_BF16X3>(cst, rb, order, cst_row, l_of_d, W1, W2, gate, src_p, n_edges, n_orb, C, V, n_l,
+  return coeff_mlp_contract_lowp<PREC_BF16X3>(cst16, rb, order, cst_row, l_of_d, W1, W2, gate, src_p, n_edges, n_orb, C, V, n_l,
                                               A, B, Ag, gram, workspace, ws_bytes, stream);
 }
 
-extern "C" int lcao_coeff_mlp_contract_f16(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
+extern "C" int lcao_coeff_mlp_contract_f16(const void* cst16, const float* rb, const int32_t* order, const int32_t* cst_row,
                                            const int32_t* l_of_d, const float* W1, const float* W2, const float* gate,
                                            const int32_t* src_p, int64_t n_edges, int n_orb, int C, int V, int n_l, float* A,
                                            float* B, float* Ag, float* gram, void* workspace, size_t ws_bytes, void* stream) {
-  return coeff_mlp_contract_lowp<PREC_F16>(cst, rb, order, cst_row, l_of_d, W1, W2, gate, src_p, n_edges, n_orb, C, V, n_l, A,
+  return coeff_mlp_contract_lowp<PREC_F16>(cst16, rb, order, cst_row, l_of_d, W1, W2, gate, src_p, n_edges, n_orb, C, V, n_l, A,
                                            B, Ag, gram, workspace, ws_bytes, stream);
 }
 
@@ -316,10 +652,10 @@ __global__ __launch_bounds__(256) void k_edge_lcao_weight_lowp(const float* __re
                                                                const float* __restrict__ W3, const float* __restrict__ Wb,
                                                                int64_t E, float* __restrict__ bw) {
   typedef typename LowP<PREC>::T T;
-  constexpr int MT = V / 16, KS = V / 32, LD = V + 8, NP = LowP<PREC>::PLANES;
+  constexpr int MT = V / 16, KS = V / 32, NP = LowP<PREC>::PLANES;
   extern __shared__ unsigned char lds_raw[];
   T* w3p = (T*)lds_raw;
-  T* wbp = w3p + NP * V * LD;
+  T* wbp = w3p + NP * V * V;
   stage_weights_lowp<PREC, false>(w3p, W3, V, V);
   stage_weights_lowp<PREC, true>(wbp, Wb, V, V);
   __syncthreads();
@@ -345,7 +681,10 @@ __global__ __launch_bounds__(256) void k_edge_lcao_weight_lowp(const float* __re
     f32x4v ft[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) ft[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    lowp_layer<PREC, KS, MT>(w3p, V, LD, r, q, xin, ft);
+    LowpOperand<PREC> xop[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xop[s].set(xin[s]);
+    lowp_layer<PREC, KS, MT>(w3p, V, V, r, q, xop, ft);
     float n2 = 0.f;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -369,7 +708,10 @@ __global__ __launch_bounds__(256) void k_edge_lcao_weight_lowp(const float* __re
     f32x4v o[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) o[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    lowp_layer<PREC, KS, MT>(wbp, V, LD, r, q, lin, o);
+    LowpOperand<PREC> lop[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) lop[s].set(lin[s]);
+    lowp_layer<PREC, KS, MT>(wbp, V, V, r, q, lop, o);
     if (valid) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) *(f32x4v*)(bw + p * V + 16 * m + 4 * q) = o[m];
@@ -384,7 +726,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_lowp(
     const float* __restrict__ bn2, int64_t E, const int32_t* __restrict__ skip_if /* nullable: return when it reads 1 */,
     float* __restrict__ msg) {
   typedef typename LowP<PREC>::T T;
-  constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
+  constexpr int MT = V / 16, KS = V / 32;
   extern __shared__ unsigned char lds_raw[];
   if (skip_if && *skip_if != 0) return;
   T* wp = (T*)lds_raw;
@@ -411,7 +753,10 @@ __global__ __launch_bounds__(256) void k_edge_node_message_lowp(
     f32x4v o[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
-    lowp_layer<PREC, KS, MT>(wp, V, LD, r, q, hin, o);
+    LowpOperand<PREC> hop[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) hop[s].set(hin[s]);
+    lowp_layer<PREC, KS, MT>(wp, V, V, r, q, hop, o);
     if (valid) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -434,7 +779,7 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols_lowp(
     const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr, const float* __restrict__ Wn2,
     const float* __restrict__ bn2, int n_nodes, int n_edges, const int32_t* __restrict__ hint, float* __restrict__ agg) {
   typedef typename LowP<PREC>::T T;
-  constexpr int MT = V / 16, KS = V / 32, LD = V + 8;
+  constexpr int MT = V / 16, KS = V / 32;
   extern __shared__ unsigned char lds_raw[];
   if (hint && *hint == 0) return;
   const bool by_degree = hint && *hint == 2;
@@ -497,7 +842,10 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols_lowp(
         for (int m = 0; m < MT; ++m) wv[m] = *(const f32x4v*)(bw + pw * V + 16 * m + 4 * q);
 #pragma unroll
         for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
-        lowp_layer<PREC, KS, MT>(wp, V, LD, r, q, hin, o);
+        LowpOperand<PREC> hop[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) hop[s].set(hin[s]);
+    lowp_layer<PREC, KS, MT>(wp, V, V, r, q, hop, o);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -546,7 +894,7 @@ static int edge_lcao_weight_lowp(const float* tbw, const float* B, const float* 
   if (n_edges == 0) return LCAO_OK;
   LCAO_CHECK_PTR(tbw); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(W3); LCAO_CHECK_PTR(Wb); LCAO_CHECK_PTR(bw);
   hipStream_t st = (hipStream_t)stream;
-  size_t lds = size_t(2) * LowP<PREC>::PLANES * V * (V + 8) * 2;
+  size_t lds = size_t(2) * LowP<PREC>::PLANES * V * V * 2;
 #define LWL_CASE(V_)                                                                                                \
   if (V == V_) {                                                                                                    \
     static bool done = false;                                                                                       \
@@ -571,7 +919,7 @@ static int edge_node_message_lowp(const float* bw, const float* Ps, const float*
   LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p);
   LCAO_CHECK_PTR(Wn2); LCAO_CHECK_PTR(bn2); LCAO_CHECK_PTR(msg);
   hipStream_t st = (hipStream_t)stream;
-  size_t lds = size_t(LowP<PREC>::PLANES) * V * (V + 8) * 2;
+  size_t lds = size_t(LowP<PREC>::PLANES) * V * V * 2;
 #define NML_CASE(V_)                                                                                                 \
   if (V == V_) {                                                                                                     \
     static bool done = false;                                                                                        \
@@ -627,7 +975,7 @@ static int edge_node_message_agg_lowp(const float* bw, const float* Ps, const fl
   hipLaunchKernelGGL(k_rows_segment_sum, dim3(lcao_blocks(n_nodes, 4, 65536)), dim3(256), 0, st, msg, out_ptr, (int)n_nodes, V,
                      column_hint, agg);
   if (!column_hint) return lcao_launch_status();
-  size_t lds = size_t(LowP<PREC>::PLANES) * V * (V + 8) * 2;
+  size_t lds = size_t(LowP<PREC>::PLANES) * V * V * 2;
   int64_t per_cu = (lds > 80 * 1024) ? 1 : ((lds > 53 * 1024) ? 2 : 3);
   int64_t cgroups = (((n_nodes + 15) >> 4) + 3) / 4, cap = (int64_t)lcao_num_cu() * per_cu;
   if (cgroups > cap) cgroups = cap;

@@ -43,8 +43,14 @@ class CapturedForward:
             for _ in range(max(warmup, 1)):                  # one-time initialisation (kernel attributes, allocator pools)
                 model(self.static, **forward_kwargs)
         torch.cuda.current_stream().wait_stream(side)
+        # z and the edge list are fixed for the life of a capture, so the index checks of the warm-up calls are final:
+        # a bad atomic number or node id raises HERE (a replay never publishes the flag)
+        from .. import ops
+        ops.publish_errors(pos.device)
+        ops.raise_pending_errors(pos.device, sync=True)
         self.hip_graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.hip_graph):
+        self.workspaces: list = []     # tile-queue words of the captured coefficient launches: live and die with this object
+        with torch.no_grad(), ops.capture_workspaces(self.workspaces), torch.cuda.graph(self.hip_graph):
             self.outputs = model(self.static, **forward_kwargs)
 
     def __call__(self, pos: Tensor | None = None, lattice: Tensor | None = None):

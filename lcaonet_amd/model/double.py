@@ -147,7 +147,7 @@ class _Geo:
         basis and coefficient rows (ghost-centred in-edges feed the three-body term)."""
         from .lcaonet import EdgeContext
 
-        z = graph[GraphKeys.Z]
+        z = model.checked_z(graph)
         dev = z.device
         self.z, self.N = z, z.numel()
         ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], self.N)
@@ -599,8 +599,11 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
     x = gather(x_tab, geo.zplan)                                              # (N, H)
     mask_pair = model.pair_valence_mask(geo.zdim).unsqueeze(-1) if model.add_valence else None
     for li, layer in enumerate(model.int_layers):
-        if shard is not None and li > 0 and plan.n_ghost:
-            x = torch.cat([x, shard[1](x)], dim=0)                            # halo rows of the previous layer's output
+        if shard is not None and li > 0:
+            # halo rows of the previous layer's output.  Entered by EVERY rank, also one without ghosts of its own (it may
+            # still have rows to send, and its peers wait in the same collective — forward and, through the adjoint, in
+            # backward); exchange_ghosts returns at once only when the rank neither sends nor receives
+            x = torch.cat([x, shard[1](x)], dim=0)
         nw = dense(x, layer.node_weight.weight, layer.node_weight.bias)
         xs, xk = nw[:, :V], nw[:, V:]
         gate = torch.sigmoid(xk)
@@ -667,7 +670,7 @@ def forward_exact_forces(model, graph, update_stats: bool = True, tables=None):
     in model/train.py)."""
     from .train import species_tables_autograd
 
-    z = graph[GraphKeys.Z]
+    z = model.checked_z(graph)
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(graph[GraphKeys.Pos], "graph.pos")
     x_tab, cst_pair = tables if tables is not None else species_tables_autograd(model, z, idx_s, idx_t, update_stats)[:2]
@@ -684,7 +687,7 @@ def forward_generic(model, graph, update_stats: bool = True):
     does not cover — any activation module (lcaonet/nn/activation.py), any BaseCutoff — through the same primitives."""
     from .train import species_tables_autograd
 
-    z = graph[GraphKeys.Z]
+    z = model.checked_z(graph)
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(graph[GraphKeys.Pos], "graph.pos")
     x_tab, cst_pair, _, _ = species_tables_autograd(model, z, idx_s, idx_t, update_stats)
@@ -712,7 +715,7 @@ def forward_sharded_differentiable(model, plan, group=None, update_stats: bool =
     if model.regress_forces:
         raise NotImplementedError("sharded training: energies only")
     g = plan.graph
-    z = g[GraphKeys.Z]
+    z = model.checked_z(g)
     idx_s, idx_t = g[GraphKeys.Edge_idx]
     own_e = idx_s < plan.n_own
     exchange = exchange or (lambda x_own: sh.halo_exchange(x_own, plan, group))

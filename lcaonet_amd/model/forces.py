@@ -183,7 +183,7 @@ def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
             out, force = forward_exact_forces(model, graph, update_stats=False)
         return out.detach(), force.detach()
     batch_idx = graph.get(GraphKeys.Batch_idx)
-    z, pos = graph[GraphKeys.Z], graph[GraphKeys.Pos]
+    z, pos = model.checked_z(graph), graph[GraphKeys.Pos]
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(pos, "graph.pos")
     N = z.size(0)
@@ -276,7 +276,7 @@ def sharded_force_steps(model, plan):
 
     _check_supported(model)
     graph = plan.graph
-    z, pos = graph[GraphKeys.Z], graph[GraphKeys.Pos]
+    z, pos = model.checked_z(graph), graph[GraphKeys.Pos]
     ops._dev(pos, "plan.graph.pos")
     n_own, e_own, n_loc = plan.n_own, plan.e_own, z.size(0)
     ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], n_loc)

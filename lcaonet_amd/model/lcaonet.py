@@ -30,7 +30,7 @@ from torch import Tensor
 from .. import ops
 from ..atomistic.info import ElecInfo
 from ..data.keys import GraphKeys
-from ..nn.base import Dense, act_code, inference_only, run_mlp
+from ..nn.base import Dense, act_code, drop_weight_caches, inference_only, run_mlp
 from ..nn.cutoff import BaseCutoff
 from ..nn.embed import EmbedCoeffs, EmbedElec, EmbedNode, EmbedZ, ValenceMask
 from ..nn.post import PostProcess
@@ -106,6 +106,15 @@ class LCAOEmbedding(nn.Module):
         self.node_embed = EmbedNode(emb_size, emb_size, use_elec, self.emb_size_node_e, activation, weight_init)
         self.coeff_embed = EmbedCoeffs(emb_size_coeff, emb_size_coeff, emb_size_coeff, elec_info.n_orb, activation,
                                        weight_init)
+
+    # weight-derived caches (see LCAONet.invalidate_caches): dropped by everything that rewrites weights wholesale
+    def train(self, mode: bool = True):
+        drop_weight_caches(self)
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        drop_weight_caches(self)
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, z: Tensor, idx_s: Tensor, idx_t: Tensor) -> tuple[Tensor, Tensor]:
         z_embed = self.z_embed(z)
@@ -235,6 +244,15 @@ class LCAOInteraction(nn.Module):
         return self.out_weight(scatter(msg, idx_s, dim=0, dim_size=N), residual=x)
 
     # ------------------------------------------------------------------ fused graph path
+    # weight-derived caches (see LCAONet.invalidate_caches): dropped by everything that rewrites weights wholesale
+    def train(self, mode: bool = True):
+        drop_weight_caches(self)
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        drop_weight_caches(self)
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _fusable(self, C: int) -> bool:
         V = self.emb_size_conv
         acts_silu = all(type(m) is nn.SiLU for m in (self.f_coeffs[1], self.f_coeffs[3], self.f_node[1], self.f_node[3]))
@@ -281,8 +299,10 @@ class LCAOInteraction(nn.Module):
                       ctx: EdgeContext, l_of_d: Tensor, n_l: int, fused: bool | None = None,
                       trace: dict | None = None, exact_norm: bool = False, n_own: int | None = None,
                       e_own: int | None = None, pair: tuple | None = None, precision: str = "fp32",
-                      ghost_fn=None, cst_row: Tensor | None = None) -> Tensor:
+                      ghost_fn=None, cst_row: Tensor | None = None, cst16: Tensor | None = None) -> Tensor:
         """x (N,H), cst (E,D,C) and rb (E,D), uvec (E,3) in the caller's edge order; valence_ed (E,D) 0/1.
+
+        cst16 (16-bit precisions): ops.lowp_pack_rows(cst, precision), packed once per forward by the caller.
 
         cst_row (int32, p-space; fused kernels only): cst is then a TABLE of coefficient rows and edge p reads row
         cst_row[p] — the gather is fused into lcao_coeff_mlp_contract and nothing of size (E, D, C) exists.
@@ -346,7 +366,7 @@ class LCAOInteraction(nn.Module):
             # BASELINE config 3: 16-bit MFMA on the per-edge coefficient GEMMs (bf16 split in two terms, or plain fp16)
             Ag, gram, B, Bv = ops.coeff_mlp_contract_bf16x3(
                 cst, rb, ctx.order, l_of_d, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(), n_l,
-                gate=None if exact_norm else gate, src_p=ctx.src_p, cst_row=cst_row, precision=precision)
+                gate=None if exact_norm else gate, src_p=ctx.src_p, cst_row=cst_row, precision=precision, cst16=cst16)
             if exact_norm:
                 tbw = ops.triplet_sum(Ag, gate, uvec, ctx.order, ctx.src_p, in_ptr, ctx.in_pos, e_own)
             else:
@@ -482,6 +502,43 @@ class LCAONet(BaseMPNN):
         self.out_layer = LCAOOut(emb_size, out_size, is_extensive, regress_forces, direct_forces, act, wi)
         self.pp_layer = PostProcess(out_size, is_extensive, atomref, mean)
 
+    # --- weight-derived caches ------------------------------------------------------------------------------
+    # The eval-mode species / pair tables (LCAOEmbedding.species_tables) and the folded node weights
+    # (LCAOInteraction._folded_node_weights) are functions of the weights only and are kept between forwards, keyed on
+    # (data_ptr, _version) of every tensor they were built from.  Optimiser steps, load_state_dict and the package's
+    # initialisers write in place on the parameter and bump the version; a write THROUGH `.data` (`p.data.copy_(ema)`)
+    # does not, so everything that replaces weights wholesale drops the caches here — and code that edits `.data`
+    # directly calls invalidate_caches().
+    def checked_z(self, graph) -> Tensor:
+        """The graph's atomic numbers range-checked and CLAMPED to [1, max_z] on the device (the reference indexes its
+        embedding tables with z - 1 and raises IndexError, embed.py:41); a value outside sets the device error flag that
+        forward() publishes.  Every entry point — inference, forces, training, sharded — reads z through this."""
+        return ops.checked_index(graph[GraphKeys.Z], 1, self.emb_layer.max_z, ops.FLAG_ATOMIC_NUMBER)
+
+    def invalidate_caches(self) -> None:
+        """Forget the weight-derived tables; the next forward rebuilds them.  Call after writing weights through `.data`."""
+        drop_weight_caches(self)
+
+    def train(self, mode: bool = True):
+        drop_weight_caches(self)
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        drop_weight_caches(self)
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):     # .to(device) / .float() / .half(): the tables live on the old device
+        drop_weight_caches(self)
+        return super()._apply(fn, *args, **kwargs)
+
+    def reset_parameters(self) -> None:
+        """Re-initialise every sub-module that has a reset_parameters() (the reference's modules initialise themselves
+        in __init__; this is the same call repeated) and drop the weight-derived caches."""
+        for m in self.modules():
+            if m is not self and hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        drop_weight_caches(self)
+
     # --- index / geometry helpers with the reference's names -------------------------------------------
     @torch.no_grad()
     def get_triplets(self, graph):
@@ -530,11 +587,16 @@ class LCAONet(BaseMPNN):
         if self.training:
             raise NotImplementedError("forward_sharded is the inference path (eval mode); single-graph training: "
                                       "forward_sharded_train(plan, group)")
+        dev = plan.graph[GraphKeys.Pos].device
+        if dev.type == "cuda":
+            ops.raise_pending_errors(dev)
         if self.regress_forces and not self.direct_forces:
             # F = -dE/dpos of the owned atoms: sharded reverse sweep with L reverse halo exchanges (model/forces.py)
             from .forces import run_sharded_forces
 
-            return run_sharded_forces(self, plan, group, exchange_fn, reduce_fn, reverse_fn)
+            res = run_sharded_forces(self, plan, group, exchange_fn, reduce_fn, reverse_fn)
+            self._publish_index_errors(dev)
+            return res
         reduce_fn = reduce_fn or (lambda part: shard.reduce_graph_outputs(part, group))
         sf = ShardedForward(self, plan, fused)
         pending = None
@@ -550,7 +612,8 @@ class LCAONet(BaseMPNN):
         out = sf.finish(reduce_fn(sf.head_partial()))
         if self.regress_forces:   # direct forces of the owned centres (their out-edges are all local)
             ghosts = exchange_fn(x_own) if exchange_fn is not None else shard.exchange_ghosts(plan, x_own, group)
-            return out, sf.direct_forces(ghosts)
+            out = (out, sf.direct_forces(ghosts))
+        self._publish_index_errors(dev)
         return out
 
     def forward_sharded_train(self, plan, group=None, **kw):
@@ -560,7 +623,12 @@ class LCAONet(BaseMPNN):
         See model/double.py::forward_sharded_differentiable."""
         from .double import forward_sharded_differentiable
 
-        return forward_sharded_differentiable(self, plan, group, **kw)
+        dev = plan.graph[GraphKeys.Pos].device
+        if dev.type == "cuda":
+            ops.raise_pending_errors(dev)
+        out = forward_sharded_differentiable(self, plan, group, **kw)
+        self._publish_index_errors(dev)
+        return out
 
     # --- forward ------------------------------------------------------------------------------------------
     def forward(self, graph, fused: bool | None = None, materialize_triplets: bool = False,
@@ -590,19 +658,31 @@ class LCAONet(BaseMPNN):
                               or cst_mode != "edge" or precision != "fp32" or edge_context is not None)
             differentiable = (torch.is_grad_enabled() and not inference_only
                               and any(p.requires_grad for p in self.parameters()))
-        if differentiable:
-            from .train import forward_differentiable
-
-            return forward_differentiable(self, graph)
         if precision not in ("fp32",) + ops.LOWP:
             raise ValueError(f"precision={precision!r}: expected 'fp32', 'bf16x3' or 'f16'")
         dev = graph[GraphKeys.Pos].device
         if dev.type == "cuda":
             ops.raise_pending_errors(dev)            # an earlier forward that has finished and flagged a bad index
-        out = self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision,
-                                      edge_context)
-        ops.publish_errors(dev)                      # this forward's flag: asynchronous copy, read when it has landed
+        if differentiable:
+            from .train import forward_differentiable
+
+            out = forward_differentiable(self, graph)
+        else:
+            out = self._forward_inference(graph, fused, materialize_triplets, trace, exact_norm, cst_mode, precision,
+                                          edge_context)
+        self._publish_index_errors(dev)
         return out
+
+    strict_indices: bool = False
+
+    def _publish_index_errors(self, dev) -> None:
+        """This call's index-error flag: an asynchronous copy to pinned memory, turned into LcaoHipError by the next call
+        once it has landed — or, with `model.strict_indices = True`, before this call returns (one device sync)."""
+        if dev.type != "cuda":
+            return
+        ops.publish_errors(dev)
+        if self.strict_indices:
+            ops.raise_pending_errors(dev, sync=True)
 
     @torch.no_grad()
     def pair_valence_mask(self, zdim: int) -> Tensor:
@@ -652,7 +732,7 @@ class LCAONet(BaseMPNN):
         idx_s, idx_t = edge_index[0], edge_index[1]
         ops._dev(pos, "graph.pos")
         # atomic numbers range-checked and clamped on the device (embed.py:41 indexes z - 1; the reference raises)
-        z = ops.checked_index(graph[GraphKeys.Z], 1, self.emb_layer.max_z, ops.FLAG_ATOMIC_NUMBER)
+        z = self.checked_z(graph)
         N = z.size(0)
 
         # edge_context: the index structures of this edge list built earlier (EdgeContext.build) — they do not depend on
@@ -682,6 +762,12 @@ class LCAONet(BaseMPNN):
         else:
             x, cst = self.emb_layer.forward_species(z, ctx)
         valence_ed = self.valence_mask.per_edge(z, idx_t) if self.add_valence else None
+        # 16-bit coefficient kernels: the MFMA operands of cst, prepared once (cst is the same in every interaction)
+        cst16 = None
+        if (precision in ops.LOWP and pair is None and fused is not False and not self.add_valence
+                and self.emb_size_coeff == self.emb_size_conv
+                and all(layer._fusable(self.emb_size_coeff) for layer in self.int_layers)):
+            cst16 = ops.lowp_pack_rows(cst, precision)
 
         if trace is not None:
             # cst: the per-edge tensor the reference holds (materialised for the trace only); pair table in cst_mode="pair"
@@ -690,7 +776,7 @@ class LCAONet(BaseMPNN):
         for i, inte in enumerate(self.int_layers):
             tr = {} if trace is not None else None
             x = inte.forward_fused(x, cst, valence_ed, rb, uvec, ctx, self.shbf.l_of_d, self.n_l, fused, tr, exact_norm,
-                                   pair=pair, precision=precision, cst_row=cst_row)
+                                   pair=pair, precision=precision, cst_row=cst_row, cst16=cst16)
             if trace is not None:
                 trace[f"x{i + 1}"] = x
                 trace[f"three_body_w{i + 1}"] = tr["three_body_w"]

@@ -23,7 +23,7 @@ class ShardedForward:
 
         self.model, self.plan, self.fused = model, plan, fused
         graph = plan.graph
-        z = graph[GraphKeys.Z]
+        z = model.checked_z(graph)
         self.z = z
         self.ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], z.size(0))
         _, self.uvec, self.rb = model.geometry_and_basis(graph, self.ctx)

@@ -79,9 +79,10 @@ def species_tables_autograd(model, z: Tensor, idx_s: Tensor, idx_t: Tensor, upda
     zd = Z + 1
     z_cnt = z if n_own is None else z[:n_own]
     N, E = z_cnt.numel(), idx_s.numel()
-    cnt_z = torch.zeros(zd, device=dev).scatter_add_(0, z_cnt, torch.ones(N, device=dev))
+    # histograms by integer counting (torch.bincount): exact, the same in every run — no floating-point atomics
+    cnt_z = torch.bincount(z_cnt, minlength=zd).to(torch.float32)
     pair = z[idx_s] * zd + z[idx_t]
-    cnt_p = torch.zeros(zd * zd, device=dev).scatter_add_(0, pair, torch.ones(E, device=dev))
+    cnt_p = torch.bincount(pair, minlength=zd * zd).to(torch.float32)
     if count_reduce is not None:
         tot = count_reduce(torch.cat([cnt_z, cnt_p]))
         cnt_z, cnt_p = tot[:zd], tot[zd:]
@@ -111,7 +112,7 @@ class _Geom:
         from .base import BaseMPNN
         from .lcaonet import EdgeContext
 
-        z = graph[GraphKeys.Z]
+        z = model.checked_z(graph)
         self.z = z
         self.N = z.numel()
         self.ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], self.N)
@@ -306,7 +307,7 @@ def forward_differentiable(model, graph, update_stats: bool = True, energy_only:
         return forward_generic(model, graph, update_stats)
     if unsupported_reason(model) is not None:
         raise NotImplementedError(unsupported_reason(model))
-    z = graph[GraphKeys.Z]
+    z = model.checked_z(graph)
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(graph[GraphKeys.Pos], "graph.pos")
     batch_idx = graph.get(GraphKeys.Batch_idx)
@@ -329,29 +330,33 @@ def forward_differentiable(model, graph, update_stats: bool = True, energy_only:
     # heads: N-level MLPs and the per-graph reduction as torch ops under autograd
     ol = model.out_layer
     prop = _mlp(ol.out_lin, x)
+    # Per-graph sums and the direct-force scatter as sorted-segment reductions (double.py: gather <-> scatter_sum, each the
+    # other's backward): rows are added in a fixed order, so outputs AND gradients are the same bits in every run.  (These
+    # were index_add_ calls — atomicAdd on ROCm — until round 3.)
+    from .double import IndexPlan, gather, scatter_sum
     if batch_idx is not None:
         from .base import num_graphs
         B = num_graphs(graph, batch_idx)
-        out = torch.zeros(B, prop.shape[1], device=prop.device).index_add_(0, batch_idx, prop)
-        cnt = torch.zeros(B, device=prop.device).index_add_(0, batch_idx, torch.ones_like(batch_idx, dtype=prop.dtype))
+        bplan = IndexPlan(batch_idx, B)
+        out = scatter_sum(prop, bplan)
+        cnt = (bplan.ptr[1:] - bplan.ptr[:-1]).to(prop.dtype)
         if not ol.is_extensive:
             out = out / cnt.clamp(min=1).unsqueeze(1)
     else:
-        B = 1
+        B, bplan = 1, None
         out = prop.sum(0, keepdim=True) if ol.is_extensive else prop.mean(0, keepdim=True)
         cnt = torch.full((1,), float(z.numel()), device=prop.device)
     pp = model.pp_layer
     if pp.atomref is not None:
-        aref = pp.atomref[z]
-        a = torch.zeros(B, aref.shape[1], device=prop.device).index_add_(0, batch_idx, aref) if batch_idx is not None \
-            else aref.sum(0, keepdim=True)
+        aref = pp.atomref[z].float().contiguous()
+        a = scatter_sum(aref, bplan) if bplan is not None else aref.sum(0, keepdim=True)
         out = out + (a if pp.is_extensive else a / cnt.clamp(min=1).unsqueeze(1))
     if pp.mean is not None:
         out = out + (pp.mean.unsqueeze(0) * cnt.unsqueeze(1) if pp.is_extensive else pp.mean.unsqueeze(0))
     if model.regress_forces and not energy_only:  # direct forces head (lcaonet.py:303-308)
-        f = _mlp(ol.out_lin_force, torch.cat([x[idx_s], x[idx_t]], dim=-1)) * geom.uvec
-        force = torch.zeros(z.numel(), 3, device=f.device).index_add_(0, idx_s, f)
-        return out, force
+        splan, tplan = IndexPlan(idx_s, z.numel()), IndexPlan(idx_t, z.numel())
+        f = _mlp(ol.out_lin_force, torch.cat([gather(x, splan), gather(x, tplan)], dim=-1)) * geom.uvec
+        return out, scatter_sum(f.contiguous(), splan)
     return out
 
 
@@ -422,7 +427,7 @@ def forward_force_training(model, graph, max_displacement: float = 0.01):
 
         return forward_exact_forces(model, graph)
     out = forward_differentiable(model, graph, True, True)          # energies: exact first-order path, BN stats updated
-    z = graph[GraphKeys.Z]
+    z = model.checked_z(graph)
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     with torch.no_grad():                                           # forces at the same train-mode batch statistics
         x_tab, cst_pair, _, zd = species_tables_autograd(model, z, idx_s, idx_t, False)

@@ -23,6 +23,19 @@ def act_code(activation: nn.Module | None) -> int | None:
     return None
 
 
+# Weight-derived caches kept in a module's __dict__ (never in state_dict): LCAOEmbedding's species / pair tables and
+# LCAOInteraction's folded node weights.  They are keyed on (data_ptr, _version) of the tensors they were built from,
+# which an in-place write THROUGH `.data` does not change — so everything that rewrites weights wholesale drops them.
+WEIGHT_CACHE_KEYS = ("_species", "_fold")
+
+
+def drop_weight_caches(module) -> None:
+    """Forget every weight-derived cache below `module` (they are rebuilt by the next forward)."""
+    for m in module.modules():
+        for k in WEIGHT_CACHE_KEYS:
+            m.__dict__.pop(k, None)
+
+
 class Dense(nn.Linear):
     def __init__(self, in_dim: int, out_dim: int, bias: bool = True,
                  weight_init: Callable[[Tensor], Tensor] | None = None,

@@ -342,13 +342,33 @@ def coeff_contract(cstf, rb, order, l_of_d, mask, V, n_l, valence):
 LOWP = ("bf16x3", "f16")    # precision modes of the 16-bit matrix path (csrc/lcao_lowp.hip)
 
 
-def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, src_p=None, cst_row=None, precision="bf16x3"):
+_PREC_CODE = {"bf16x3": 0, "f16": 1}    # LCAO_PREC_* of include/lcaonet_hip.h
+
+
+def lowp_pack_rows(rows: Tensor, precision: str) -> Tensor:
+    """MFMA operands of the 16-bit coefficient kernels (lcao_lowp_pack_rows): per 8 values 16 bytes of fp16 ("f16") or 8
+    bf16 high + 8 bf16 low terms ("bf16x3").  `rows`: (..., C) fp32 with C % 32 == 0; returns a flat uint8 tensor."""
+    rows = _f32(rows, "rows")
+    if rows.shape[-1] % 32:
+        raise ValueError(f"lowp_pack_rows: rows of {rows.shape[-1]} values (need a multiple of 32)")
+    code = _PREC_CODE[precision]
+    n = rows.numel()
+    out = torch.empty(_lib.load().lcao_lowp_packed_bytes(n, code), device=rows.device, dtype=torch.uint8)
+    _call("lcao_lowp_pack_rows", _p(rows), n, code, _p(out), _stream())
+    return out
+
+
+def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, src_p=None, cst_row=None, precision="bf16x3",
+                              cst16=None):
     """16-bit-MFMA variant of coeff_mlp_contract (precision "bf16x3": split operands, ~1e-5; "f16": one fp16 MFMA per
-    product, ~3e-4); same outputs (no valence)."""
-    cst, rb, W1, W2 = _f32(cst, "cst"), _f32(rb, "rb"), _f32(W1), _f32(W2)
+    product, ~3e-4); same outputs (no valence).  cst16: `lowp_pack_rows(cst, precision)` when the caller has it (cst is
+    the same tensor in every interaction, so LCAONet packs it once per forward); otherwise it is packed here."""
+    rb, W1, W2 = _f32(rb, "rb"), _f32(W1), _f32(W2)
     E, D = rb.shape
     V, C = W1.shape
     dev = rb.device
+    if cst16 is None:
+        cst16 = lowp_pack_rows(cst, precision)
     B = torch.empty(E, V, device=dev, dtype=torch.float32)
     gated = gate is not None
     A = None if gated else torch.empty(E, n_l, V, device=dev, dtype=torch.float32)
@@ -357,7 +377,7 @@ def coeff_mlp_contract_bf16x3(cst, rb, order, l_of_d, W1, W2, n_l, gate=None, sr
     if gated:
         gate = _f32(gate, "gate")
     ws = tile_queue_workspace(dev)
-    _call("lcao_coeff_mlp_contract_" + precision, _p(cst), _p(rb), _p(order), _p(cst_row), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
+    _call("lcao_coeff_mlp_contract_" + precision, _p(cst16), _p(rb), _p(order), _p(cst_row), _p(l_of_d), _p(W1), _p(W2), _p(gate), _p(src_p), E,
           D, C, V, n_l, _p(A), _p(B), _p(Ag), _p(gram), _p(ws), 16, _stream())
     return (Ag if gated else A), gram, B, None
 
@@ -404,18 +424,37 @@ def pair_rows(z: Tensor, src_p: Tensor, dst_p: Tensor, zdim: int) -> Tensor:
 
 
 _TILE_WS: dict = {}
-_TILE_WS_CAPTURED: list = []
+_TILE_WS_CAPTURED: list = []      # captures made outside CapturedForward (a bare torch.cuda.graph): kept for the process
+_TILE_WS_SINK: list | None = None
+
+
+class capture_workspaces:
+    """with ops.capture_workspaces(lst): the tile-queue workspaces allocated while a HIP graph is being captured inside this
+    block are appended to `lst` — the capturing object keeps them alive exactly as long as its graph (CapturedForward)."""
+
+    def __init__(self, sink: list):
+        self.sink = sink
+
+    def __enter__(self):
+        global _TILE_WS_SINK
+        self.prev, _TILE_WS_SINK = _TILE_WS_SINK, self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        global _TILE_WS_SINK
+        _TILE_WS_SINK = self.prev
 
 
 def tile_queue_workspace(dev) -> Tensor:
     """The 16-byte tile queue of the persistent coefficient kernels (include/lcaonet_hip.h): zero on first use, left zero
     by every launch.  One per (device, stream), kept for the life of the process — launches on one stream are ordered, and
     an address that is never freed can be baked into a captured HIP graph.  While a graph is being captured a fresh
-    workspace is taken from the capture's pool and kept alive, so replays of different captures never share one."""
+    workspace is taken from the capture's pool and kept alive by the capturing object (capture_workspaces), so replays of
+    different captures never share one and a destroyed capture releases its words."""
     dev = torch.device(dev)
     if torch.cuda.is_current_stream_capturing():
         ws = torch.zeros(4, device=dev, dtype=torch.int32)
-        _TILE_WS_CAPTURED.append(ws)
+        (_TILE_WS_SINK if _TILE_WS_SINK is not None else _TILE_WS_CAPTURED).append(ws)
         return ws
     key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
     ws = _TILE_WS.get(key)

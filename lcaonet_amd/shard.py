@@ -214,8 +214,8 @@ def start_exchange(plan: ShardPlan, x_own: Tensor, group=None, out: Tensor | Non
     """Launch ONE all-to-all of boundary rows (backend 'nccl' = RCCL over xGMI on ROCm; 'gloo' on CPU).  `out`: the
     (n_ghost, H) block to receive into (e.g. the ghost rows of the next layer's x)."""
     recv = out if out is not None else x_own.new_empty((plan.n_ghost, x_own.shape[1]))
-    if plan.world == 1 or (plan.n_ghost == 0 and plan.n_send == 0):
-        return _Pending(recv, None, None)
+    if plan.world == 1:     # a rank of a larger group ALWAYS enters (all_to_all_single is a collective of the whole group,
+        return _Pending(recv, None, None)   # also for a rank that neither sends nor receives: zero-size splits)
     send = x_own[plan.send_idx]
     work = _a2a(recv, send, plan.recv_splits, plan.send_splits, group, async_op=True)
     return _Pending(recv, work, send)
@@ -231,14 +231,14 @@ def _sum_by_owned_node(plan: ShardPlan, rows: Tensor) -> Tensor:
         from . import ops
 
         return ops.segment_sum_gather(rows.contiguous(), plan.rev_perm.to(torch.int32), plan.rev_ptr)
-    return rows.new_zeros((plan.n_own, rows.shape[1])).index_add_(0, plan.send_idx, rows)
+    return rows.new_zeros((plan.n_own, rows.shape[1])).index_add_(0, plan.send_idx, rows)   # CPU rehearsal (gloo tests)
 
 
 def reverse_exchange(plan: ShardPlan, g_ghost: Tensor, group=None) -> Tensor:
     """The forward halo exchange run backwards: every rank returns what it holds for its ghosts, every owner receives
     the rows for the nodes it sent (split sizes swapped) and sums them per node -> (n_own, W) addend (zero for interior
     nodes)."""
-    if plan.world == 1 or (plan.n_ghost == 0 and plan.n_send == 0):
+    if plan.world == 1:     # as start_exchange: every rank of a larger group enters the collective
         return g_ghost.new_zeros((plan.n_own, g_ghost.shape[1]))
     rows = g_ghost.new_empty((plan.n_send, g_ghost.shape[1]))
     _a2a(rows, g_ghost, plan.send_splits, plan.recv_splits, group)

@@ -110,7 +110,7 @@ def test_c_abi_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().lcao_abi_version() == 1
+    assert _lib.load().lcao_abi_version() == _lib.ABI_VERSION == 2
     assert b"invalid" in _lib.load().lcao_error_string(-1)
 
 

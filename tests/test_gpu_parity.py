@@ -1205,3 +1205,52 @@ def test_cfg3_f16_vs_oracle(dev, width):
     tol = 1e-3 if width == 128 else 3e-3
     assert max(e_tbw, e_x, e_out) <= tol
     assert relerr(m(g.to(dev), precision="f16", cst_mode="pair"), want) <= tol
+
+
+@pytest.mark.gpu
+def test_weight_caches_follow_weight_rewrites(dev):
+    """the species / pair tables and the folded node weights are keyed on (data_ptr, _version); writes through
+    `.data` do not bump the version.  The package's initialisers now write on the parameter itself, and train(),
+    load_state_dict, reset_parameters, .to() and invalidate_caches() drop the caches: an eval forward after any of them
+    must equal a fresh model holding the same weights."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import LCAONet
+
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=5.0)
+    g = random_periodic_cells(3, 12, 6.5, 0.99 * 5.0, seed=5).to(dev)
+
+    def fresh_like(m):
+        f = LCAONet(**kw).to(dev).eval()
+        f.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+        return f
+
+    torch.manual_seed(3)
+    m = LCAONet(**kw).to(dev).eval()
+    with torch.no_grad():
+        y0 = m(g)
+        # 1. re-initialisation through the package's initialisers (glorot_orthogonal via Dense.reset_parameters)
+        torch.manual_seed(4)
+        m.reset_parameters()
+        y1 = m(g)
+        assert not torch.allclose(y0, y1)
+        assert torch.equal(y1, fresh_like(m)(g))
+        # 2. one Dense re-initialised on its own (no model-level hook runs: the initialiser must bump the version)
+        torch.manual_seed(5)
+        m.int_layers[0].node_weight.reset_parameters()
+        m.int_layers[0].f_coeffs[0].reset_parameters()
+        y2 = m(g)
+        assert not torch.allclose(y1, y2)
+        assert torch.equal(y2, fresh_like(m)(g))
+        # 3. an EMA-style overwrite through .data followed by invalidate_caches()
+        for p_ in m.parameters():
+            p_.data.mul_(0.9)
+        m.invalidate_caches()
+        y3 = m(g)
+        assert torch.equal(y3, fresh_like(m)(g))
+        # 4. .data overwrite + train()/eval() round trip
+        for p_ in m.parameters():
+            p_.data.mul_(1.05)
+        m.train()
+        m.eval()
+        y4 = m(g)
+        assert torch.equal(y4, fresh_like(m)(g))
