@@ -261,17 +261,9 @@ __global__ void k_triplet_bwd_q(const float* __restrict__ g_tbw, const float* __
         float y[4], dy[4];
 #pragma unroll
         for (int l = 0; l < 4; ++l) { y[l] = (l < NL) ? lcao_y_l0(c, l) : 0.f; dy[l] = (l < NL) ? lcao_y_l0_grad(c, l) : 0.f; }
-        // m = Y^T G Y and (G Y)_l with upper-triangular storage idx(l,l2) = l*4 - l(l-1)/2 + (l2-l)
-        float GY[4] = {0.f, 0.f, 0.f, 0.f};
-        float m = 0.f;
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
-#pragma unroll
-          for (int l2 = l; l2 < 4; ++l2) {
-            const float gv = G[l * 4 - (l * (l - 1)) / 2 + (l2 - l)];
-            if (l == l2) { m += y[l] * y[l] * gv; GY[l] += gv * y[l]; }
-            else { m += 2.0f * y[l] * y[l2] * gv; GY[l] += gv * y[l2]; GY[l2] += gv * y[l]; }
-          }
+        // m = |R Y|^2 = Y^T A A^T Y and GY = R^T R Y from the edge's triangular factor (lcao_common.h)
+        float GY[4];
+        const float m = lcao_factor_quadratic<4>(G, y, GY);
         const float nrm = sqrtf(fmaxf(m, 0.f));
         const bool live = nrm > 1e-12f;
         const float inv = live ? 1.0f / nrm : 1e12f;

@@ -98,6 +98,71 @@ __device__ __forceinline__ float lcao_cutoff_eval(float r, float rc, int kind) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-edge triangular factor (the 10-float record the three-body kernels read).  lcaonet.py:179-184 normalises every
+// per-triplet vector v = sum_l y_l A_l directly; the fused kernels need |v| from per-EDGE data.  Round 1-2 kept the Gram
+// matrix G = A A^T and took |v|^2 = y^T G y: a difference of large terms when the A_l are correlated and v nearly cancels
+// (error eps S^2 / |v|^2, S = sum |y_l| |A_l|: 6x the literal form's on a model with rank-1 f_coeffs.2,
+// tests/test_gpu_conditioning.py).  Now the record is R (upper triangular, R^T R = A A^T) from a modified Gram-Schmidt
+// sweep over the vectors themselves, and |v|^2 = |R y|^2 = sum_i (sum_{j>=i} R[i][j] y_j)^2 — a sum of squares whose
+// inner sums cancel exactly as v does (error eps S / |v|, the literal form's).  Entry (i, j >= i) sits at lcao_tri_idx(i, j).
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int lcao_tri_idx(int l, int l2) {  // l <= l2, row-major upper triangle of a 4x4
+  return l * 4 - (l * (l - 1)) / 2 + (l2 - l);
+}
+
+// w[l][0..NVAL): this lane's values of the n_l vectors of its edge (DESTROYED); reduce(x) sums x over the lanes that share
+// the edge.  R[lcao_tri_idx(i, j)] for i <= j < NL, zero elsewhere.  A zero (or numerically dependent) vector gives a
+// zero row: its later coefficients are 0, never NaN.
+template <int NL, int NVAL, typename Reduce>
+__device__ __forceinline__ void lcao_edge_factor(float (&w)[NL][NVAL], float (&R)[10], Reduce reduce) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) R[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    float d[NL];
+#pragma unroll
+    for (int j = i; j < NL; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NVAL; ++k) t += w[i][k] * w[j][k];
+      d[j] = reduce(t);
+    }
+    const float rii = sqrtf(d[i]);
+    const float inv = rii > 0.f ? 1.0f / rii : 0.f;
+    R[lcao_tri_idx(i, i)] = rii;
+#pragma unroll
+    for (int j = i + 1; j < NL; ++j) {
+      const float rij = d[j] * inv;
+      R[lcao_tri_idx(i, j)] = rij;
+      const float f = rij * inv;
+#pragma unroll
+      for (int k = 0; k < NVAL; ++k) w[j][k] -= f * w[i][k];
+    }
+  }
+}
+
+// m = |R y|^2 (= y^T A A^T y) and Gy = R^T (R y) (= A A^T y, half the gradient of m with respect to y)
+template <int NL>
+__device__ __forceinline__ float lcao_factor_quadratic(const float (&R)[10], const float (&y)[4], float (&Gy)[4]) {
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+#pragma unroll
+    for (int j = i; j < NL; ++j) t[i] += R[lcao_tri_idx(i, j)] * y[j];
+    m += t[i] * t[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    Gy[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i <= j; ++i)
+      if (i < NL && j < NL) Gy[j] += R[lcao_tri_idx(i, j)] * t[i];
+  }
+  return m;
+}
+
 // sum within each row of 16 lanes (DPP: two quad permutes, row_half_mirror, row_mirror), result in every lane of the row
 __device__ __forceinline__ float lcao_row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

@@ -724,7 +724,7 @@ extern "C" const char* lcao_error_string(int code) {
 // lcao_pair_contract — species-pair form of f_coeffs + radial contraction.
 // cst[e] is a function of (z_s, z_t) only (embed.py:246-249) and every layer applies a row-wise MLP to the same
 // cst, so f_coeffs(cst)[e] = Tf[z_s, z_t] with Tf a ((Z+1)^2, D, V) table (5.6 MB at Z=36: L2 / Infinity-Cache
-// resident).  Per edge p:  A[l,:] = sum_{d in l} rb[e,d] * Tf[pair,d,:],  B = sum_l A,  gram = A A^T,
+// resident).  Per edge p:  A[l,:] = sum_{d in l} rb[e,d] * Tf[pair,d,:],  B = sum_l A,  gram = triangular factor of A A^T,
 // Ag[l,:] = A[l,:] * gate[src,:].   One wave per edge, lanes over V (R values per lane); 2.1 KB written per edge.
 // ---------------------------------------------------------------------------------------------------
 // 16 lanes per edge (4 edges per wave); a lane owns CH = V/16 channels as float4 chunks: chunk c covers channels
@@ -774,26 +774,17 @@ __global__ __launch_bounds__(256) void k_pair_contract(const float* __restrict__
           for (int c = 0; c < NC; ++c) a[ll][c] += w * v[c];
         }
     }
-    // Gram (upper triangle of a 4x4, row-major): in-lane partial + 16-lane row reduction
+    // triangular factor of the per-l vectors (lcao_common.h: lcao_edge_factor): in-lane partials + 16-lane row reductions
     float g[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) g[i] = 0.f;
     {
-      int gi = 0;
+      float wv[NL][4 * NC];
 #pragma unroll
-      for (int l = 0; l < 4; ++l)
+      for (int l = 0; l < NL; ++l)
 #pragma unroll
-        for (int l2 = l; l2 < 4; ++l2) {
-          if (l < NL && l2 < NL) {
-            float acc = 0.f;
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-              for (int k = 0; k < 4; ++k) acc += a[l][c][k] * a[l2][c][k];
-            g[gi] = lcao_row16_sum(acc);
-          }
-          ++gi;
-        }
+          for (int k = 0; k < 4; ++k) wv[l][4 * c + k] = a[l][c][k];
+      lcao_edge_factor<NL, 4 * NC>(wv, g, [](float t) { return lcao_row16_sum(t); });
     }
     if (valid) {
       if (sub < 10) {
@@ -853,18 +844,20 @@ __global__ void k_pair_contract_any(const float* __restrict__ Tf, const float* _
         a[2][r] += (l == 2) ? v : 0.f; a[3][r] += (l == 3) ? v : 0.f;
       }
     }
-    int gi = 0;
+    {
+      float wv[4][R], g[10];   // triangular factor (rows >= n_l are zero vectors and give zero rows)
 #pragma unroll
-    for (int l = 0; l < 4; ++l)
+      for (int l = 0; l < 4; ++l)
 #pragma unroll
-      for (int l2 = l; l2 < 4; ++l2) {
-        float acc = 0.f;
+        for (int r = 0; r < R; ++r) wv[l][r] = a[l][r];
+      lcao_edge_factor<4, R>(wv, g, [](float t) { return lcao_wave_sum(t); });
+      if (lane < 10) {
+        float gv = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc += a[l][r] * a[l2][r];
-        acc = lcao_wave_sum(acc);
-        if (lane == 0) gram[p * 10 + gi] = acc;
-        ++gi;
+        for (int i = 0; i < 10; ++i) gv = (lane == i) ? g[i] : gv;
+        gram[p * 10 + lane] = gv;
       }
+    }
     const float* gt = gate + (int64_t)s * V;
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -515,27 +515,25 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_lowp(
       }
     }
     LOWP_STAMP(7);   // gate request + B
+    if (!((LCAO_ABL & 32) && acc[0][0][0] != 12345.f)) {
+      float* Ap = (GATED ? Ag : A) + (int64_t)cur_rows.pc * NL * V + 4 * q;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) *(f32x4v*)(Ap + l * V + 16 * m) = GATED ? acc[l][m] * gt[m] : acc[l][m];
+    }
+    LOWP_STAMP(6);   // A stores
     if (GATED) {
-      float g[12];
+      // triangular factor of the ungated per-l vectors (lcao_common.h: lcao_edge_factor), in place on the accumulators
+      // after their last use above
+      float g[12], g10[10];
+      float(&wv)[NL][4 * MT] = reinterpret_cast<float(&)[NL][4 * MT]>(acc);
+      lcao_edge_factor<NL, 4 * MT>(wv, g10, [](float t) {
+        t += __shfl_xor(t, 16);
+        return t + __shfl_xor(t, 32);
+      });
 #pragma unroll
-      for (int i = 0; i < 12; ++i) g[i] = 0.f;
-      int gi = 0;
-#pragma unroll
-      for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int l2 = l; l2 < 4; ++l2) {
-          if (l < NL && l2 < NL) {
-            float t = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) t += acc[l][m][j] * acc[l2][m][j];
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            g[gi] = t;
-          }
-          ++gi;
-        }
+      for (int i = 0; i < 10; ++i) g[i] = g10[i];
       g[10] = g[9];   // lane group q stores entries q, q + 4, q + 8 (entries 10, 11 repeat entry 9): three stores, no branch
       g[11] = g[9];
       float* gp = gram + (int64_t)cur_rows.pc * 10;
@@ -546,15 +544,7 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp_lowp(
         gp[i < 10 ? i : 9] = v;
       }
     }
-    LOWP_STAMP(8);   // Gram
-    if (!((LCAO_ABL & 32) && acc[0][0][0] != 12345.f)) {
-      float* Ap = (GATED ? Ag : A) + (int64_t)cur_rows.pc * NL * V + 4 * q;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int l = 0; l < NL; ++l) *(f32x4v*)(Ap + l * V + 16 * m) = GATED ? acc[l][m] * gt[m] : acc[l][m];
-    }
-    LOWP_STAMP(6);   // A stores
+    LOWP_STAMP(8);   // edge factor
     tile = tile_n;
   }
 #ifdef LCAO_LOWP_CLK

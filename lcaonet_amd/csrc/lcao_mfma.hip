@@ -287,35 +287,6 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[l][m] += *(const f32x4v*)(Ain + l * V + 16 * m);
     }
-    if (gram) {
-      // Gram matrix of the (ungated) per-l vectors: in-lane partial over this lane's 4*MT features, then the
-      // four quarters of the edge are summed with two cross-lane steps.  G[l][l'] feeds the per-triplet norm.
-      float g[10];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) g[i] = 0.f;
-      int gi = 0;
-#pragma unroll
-      for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int l2 = l; l2 < 4; ++l2) {
-          if (l < NL && l2 < NL) {
-            float t = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) t += acc[l][m][j] * acc[l2][m][j];
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            g[gi] = t;
-          }
-          ++gi;
-        }
-      if (valid && q == 0) {
-        float* gp = gram + p * 10;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) gp[i] = g[i];
-      }
-    }
     if (valid) {
       float* Ap = A + p * (int64_t)NL * V + 4 * q;
       float* Bp = Bout + p * (int64_t)V + 4 * q;
@@ -331,6 +302,22 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
 #pragma unroll
           for (int l = 0; l < NL; ++l) *(f32x4v*)(Ap + l * V + 16 * m) = acc[l][m];
         }
+      }
+    }
+    if (gram) {
+      // triangular factor of the (ungated) per-l vectors (lcao_common.h: lcao_edge_factor), computed IN PLACE on the
+      // accumulators after their last use above: in-lane partial sums over this lane's 4*MT features, the four quarters of
+      // the edge summed with two cross-lane steps.  Feeds the per-triplet norm.
+      float(&wv)[NL][4 * MT] = reinterpret_cast<float(&)[NL][4 * MT]>(acc);
+      float g[10];
+      lcao_edge_factor<NL, 4 * MT>(wv, g, [](float t) {
+        t += __shfl_xor(t, 16);
+        return t + __shfl_xor(t, 32);
+      });
+      if (valid && q == 0) {
+        float* gp = gram + p * 10;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) gp[i] = g[i];
       }
     }
     if (!tile_counter) {   // static striding (LCAO_K2_STATIC=1: diagnostic)
@@ -1316,16 +1303,14 @@ extern "C" int lcao_lcao_weight_bwd_fused(const float* g_bw, const float* B, con
 //   accumulator tile (h, jj), lane (n, quarter), reg r  <->  out-edge n, channel 64h + 16*quarter + 4r + jj.
 //   HBM per edge: read 4*n_l*V + 40 + 12; write 4*V.
 // ===================================================================================================
-__device__ __forceinline__ int gram_idx(int l, int l2) {  // l <= l2, row-major upper triangle of a 4x4
-  return l * 4 - (l * (l - 1)) / 2 + (l2 - l);
-}
+#define gram_idx lcao_tri_idx   // entry (l, l2 >= l) of the per-edge triangular factor (lcao_common.h)
 
 // Per-triplet weights of the two 16-wide out-edge tiles of a step at once (packed fp32: .x = tile A, .y = tile B).
-// Monic angular polynomials y0' = 1, y1' = c, y2' = c^2 - Y2B/Y2A, y3' = c (c^2 - 3/5) with Y_l = s_l y_l'; the Gram
-// entries arrive PRE-SCALED, g[l,l'] = m s_l s_l' G[l,l'] (m = 2 off the diagonal; the scale is one per-lane multiply on
-// the loaded word), so  n2 = sum_{l<=l'} g[l,l'] y_l' y_l''  is a chain of packed FMAs, and the lane's own Y_quarter comes
-// from per-lane constants k_l = s_l [l == quarter] instead of a select.  ~21 VALU instructions for both weights (the
-// scalar version took ~40 each, more cycles than the 16 MFMAs they feed: fp32 MFMA and VALU share the SIMD's issue).
+// Monic angular polynomials y0' = 1, y1' = c, y2' = c^2 - Y2B/Y2A, y3' = c (c^2 - 3/5) with Y_l = s_l y_l'; the entries of
+// the edge's triangular factor arrive PRE-SCALED, g[i,j] = s_j R[i,j] (one per-lane multiply on the loaded word), so
+//     |v|^2 = |R Y|^2 = sum_i t_i^2,   t_i = sum_{j >= i} g[i,j] y_j'
+// is a chain of packed FMAs — a sum of squares (lcao_common.h: why not the Gram form) — and the lane's own Y_quarter
+// comes from per-lane constants k_l = s_l [l == quarter] instead of a select.  ~21 VALU instructions for both weights.
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 #define LCAO_Y2_SHIFT (0.31539156525252f / 0.94617469575756f)
 __host__ __device__ constexpr float trip_scale(int l) {   // s_l
@@ -1336,23 +1321,37 @@ template <int NL>
 __device__ __forceinline__ f32x2v triplet_weight2(f32x2v ux, f32x2v uy, f32x2v uz, float qx, float qy, float qz,
                                                   const float (&g)[10], const float (&k)[4], bool okA, bool okB) {
   const f32x2v c = ux * qx + uy * qy + uz * qz;
-  f32x2v n2 = {g[gram_idx(0, 0)], g[gram_idx(0, 0)]};
+  f32x2v t0 = {g[gram_idx(0, 0)], g[gram_idx(0, 0)]};
   f32x2v yq = {k[0], k[0]};
-  f32x2v c2, y2;
+  f32x2v c2, y2, n2;
+  if (NL == 1) n2 = t0 * t0;
   if (NL > 1) {
     c2 = c * c;
-    n2 += g[gram_idx(0, 1)] * c + g[gram_idx(1, 1)] * c2;
+    t0 += g[gram_idx(0, 1)] * c;
     yq += k[1] * c;
+  }
+  if (NL == 2) {
+    const f32x2v t1 = g[gram_idx(1, 1)] * c;
+    n2 = t0 * t0 + t1 * t1;
   }
   if (NL > 2) {
     y2 = c2 - LCAO_Y2_SHIFT;
-    n2 += g[gram_idx(0, 2)] * y2 + g[gram_idx(1, 2)] * (c * y2) + g[gram_idx(2, 2)] * (y2 * y2);
+    t0 += g[gram_idx(0, 2)] * y2;
     yq += k[2] * y2;
+  }
+  if (NL == 3) {
+    const f32x2v t1 = g[gram_idx(1, 1)] * c + g[gram_idx(1, 2)] * y2;
+    const f32x2v t2 = g[gram_idx(2, 2)] * y2;
+    n2 = t0 * t0 + t1 * t1 + t2 * t2;
   }
   if (NL > 3) {
     const f32x2v y3 = c * (c2 - 0.6f);
-    n2 += g[gram_idx(0, 3)] * y3 + g[gram_idx(1, 3)] * (c * y3) + g[gram_idx(2, 3)] * (y2 * y3) + g[gram_idx(3, 3)] * (y3 * y3);
+    t0 += g[gram_idx(0, 3)] * y3;
     yq += k[3] * y3;
+    const f32x2v t1 = g[gram_idx(1, 1)] * c + g[gram_idx(1, 2)] * y2 + g[gram_idx(1, 3)] * y3;
+    const f32x2v t2 = g[gram_idx(2, 2)] * y2 + g[gram_idx(2, 3)] * y3;
+    const f32x2v t3 = g[gram_idx(3, 3)] * y3;
+    n2 = t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
   }
   // 1 / max(sqrt(n2), 1e-12) = rsqrt(max(n2, 1e-24)): one v_rsq_f32 (1 ulp) instead of the IEEE sqrt + divide sequences
   f32x2v w = {__builtin_amdgcn_rsqf(fmaxf(n2[0], 1e-24f)), __builtin_amdgcn_rsqf(fmaxf(n2[1], 1e-24f))};
@@ -1376,7 +1375,7 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
 
   // One step = one in-edge q.  Everything a step needs arrives through the VECTOR memory pipe, PD steps ahead:
   //   F[h]: this lane's 16-B pieces of Ag[q, quarter, :]          (2 x global_load_dwordx4)
-  //   R   : lane i < 3 holds u_q[i], lane 3 + i holds gram[q, i]  (1 x global_load_dword, then v_readlane)
+  //   R   : lane i < 3 holds u_q[i], lane 3 + i holds entry i of the edge's triangular factor (1 x global_load_dword, then v_readlane)
   // VMEM returns in order, so a COUNTED s_waitcnt vmcnt((PD-1) x 3) leaves the later steps in flight while step j is
   // consumed — but the compiler can only count if every step issues exactly the same loads.  So nothing here is
   // conditional: lanes of quarter >= n_l read the row of the last real l (their weight is forced to zero instead), the
@@ -1385,14 +1384,14 @@ __global__ __launch_bounds__(256) void k_triplet_gemm(const float* __restrict__ 
   // Scalar (SMEM) loads would force lgkmcnt(0) on every use and sat on the critical path of each step.
   constexpr int QL = NL - 1;
   const int qrow = quarter < NL ? quarter : QL;
-  // per-lane constants: the scale of this lane's loaded word (lanes 3..12 hold gram entry lane - 3 = (l, l') in upper-
-  // triangle order) and the one-hot Y_quarter coefficients
+  // per-lane constants: the scale of this lane's loaded word (lanes 3..12 hold factor entry lane - 3 = (l, l') in upper-
+  // triangle order, scaled by s_l') and the one-hot Y_quarter coefficients
   float rscale = 1.0f;
 #pragma unroll
   for (int l = 0; l < 4; ++l)
 #pragma unroll
     for (int l2 = l; l2 < 4; ++l2)
-      if (lane - 3 == gram_idx(l, l2)) rscale = (l == l2 ? 1.0f : 2.0f) * trip_scale(l) * trip_scale(l2);
+      if (lane - 3 == gram_idx(l, l2)) rscale = trip_scale(l2);
   float kq[4];
 #pragma unroll
   for (int l = 0; l < 4; ++l) kq[l] = (quarter == l && l < NL) ? trip_scale(l) : 0.f;
@@ -1528,14 +1527,12 @@ __global__ void k_triplet_gram_any(const float* __restrict__ Ag, const float* __
         const int q = in_pos[j];
         if (q == p) continue;
         const float c = ux * uvec_p[3 * (int64_t)q] + uy * uvec_p[3 * (int64_t)q + 1] + uz * uvec_p[3 * (int64_t)q + 2];
-        float y[4], m = 0.f;
+        float y[4], Rq[10], Gy[4];
 #pragma unroll
-        for (int l = 0; l < 4; ++l) y[l] = lcao_y_l0(c, l);
-        for (int l = 0; l < NL; ++l)
-          for (int l2 = l; l2 < NL; ++l2) {
-            const float gv = gram[(int64_t)q * 10 + gram_idx(l, l2)];
-            m += (l == l2 ? 1.0f : 2.0f) * y[l] * y[l2] * gv;
-          }
+        for (int l = 0; l < 4; ++l) y[l] = l < NL ? lcao_y_l0(c, l) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) Rq[i] = gram[(int64_t)q * 10 + i];
+        const float m = lcao_factor_quadratic<4>(Rq, y, Gy);   // rows / columns >= n_l of the factor are zero
         const float inv = 1.0f / fmaxf(sqrtf(fmaxf(m, 0.f)), 1e-12f);
         for (int l = 0; l < NL; ++l) {
           const float w = y[l] * inv;
@@ -1706,15 +1703,7 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
           float y[4], dy[4], GY[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int l = 0; l < 4; ++l) { y[l] = l < NL ? lcao_y_l0(c, l) : 0.f; dy[l] = l < NL ? lcao_y_l0_grad(c, l) : 0.f; }
-          float m = 0.f;
-#pragma unroll
-          for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int l2 = l; l2 < NL; ++l2) {
-              const float gv = G[gram_idx(l, l2)];
-              if (l == l2) { m += y[l] * y[l] * gv; GY[l] += gv * y[l]; }
-              else { m += 2.0f * y[l] * y[l2] * gv; GY[l] += gv * y[l2]; GY[l2] += gv * y[l]; }
-            }
+          const float m = lcao_factor_quadratic<NL>(G, y, GY);   // G holds the edge's triangular factor: m = |R y|^2, GY = R^T R y
           const float mc = fmaxf(m, 0.f);
           const bool live = mc > 1e-24f;
           const float inv = live ? __builtin_amdgcn_rsqf(mc) : 1e12f;
@@ -1930,15 +1919,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
           float y[4], dy[4], GY[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int l = 0; l < 4; ++l) { y[l] = l < NL ? lcao_y_l0(c, l) : 0.f; dy[l] = l < NL ? lcao_y_l0_grad(c, l) : 0.f; }
-          float m = 0.f;
-#pragma unroll
-          for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int l2 = l; l2 < NL; ++l2) {
-              const float gv = G[gram_idx(l, l2)];
-              if (l == l2) { m += y[l] * y[l] * gv; GY[l] += gv * y[l]; }
-              else { m += 2.0f * y[l] * y[l2] * gv; GY[l] += gv * y[l2]; GY[l2] += gv * y[l]; }
-            }
+          const float m = lcao_factor_quadratic<NL>(G, y, GY);   // G holds the edge's triangular factor: m = |R y|^2, GY = R^T R y
           const float mc = fmaxf(m, 0.f);
           const bool live = mc > 1e-24f;
           const float inv = live ? __builtin_amdgcn_rsqf(mc) : 1e12f;
