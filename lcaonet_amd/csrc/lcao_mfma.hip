@@ -1867,20 +1867,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
           for (int t = 0; t < nit; ++t) {
             asm volatile("" ::: "memory");
             const int it = ic + 16 * t;
-            const int pa = p0 + min(it + n, m_out - 1);
-            const float* gta = g_tbw + (int64_t)pa * V + 4 * quarter;
-            f32x4v xa[KT];
-#pragma unroll
-            for (int a = 0; a < KT; ++a) xa[a] = *(const f32x4v*)(gta + 16 * a);
+            // MFMA row n of this tile is out-edge it + 4 (n % 4) + n / 4: accumulator register r of quarter qu then holds
+            // out-edge it + 4 r + qu, i.e. k-step r of GEMM 2 covers four CONSECUTIVE out-edges and a tile with few valid
+            // rows (degree 18 = 16 + 2) needs one k-step and one chain pass instead of four
             f32x4v gw[NL];
 #pragma unroll
             for (int l = 0; l < NL; ++l) gw[l] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            const int rem = m_out - it;   // wave-uniform
+            if (rem <= 4) {
+              // A tile with at most four out-edges (the 2 of a degree-18 list): its 16 x 16 MFMA tile would be 3/4 empty
+              // rows at full price (96 MFMAs).  The <= 4 x 16 x NL dot products run on the VALU instead: this lane's 32
+              // channels of its in-edge against the same channels of each out-edge row (a broadcast load per 16 lanes),
+              // then the four quarters are summed.  rem x 32 NL FMAs per lane, ~1/4 of the MFMA time at rem = 2.
 #pragma unroll
-            for (int a = 0; a < KT; ++a)
+              for (int pp = 0; pp < 4; ++pp) {
+                if (pp >= rem) break;   // wave-uniform
+                const float* gtp = g_tbw + (int64_t)(p0 + it + pp) * V + 4 * quarter;
+                f32x4v ga[KT];
 #pragma unroll
-              for (int l = 0; l < NL; ++l)
+                for (int a = 0; a < KT; ++a) ga[a] = *(const f32x4v*)(gtp + 16 * a);
+                float sl[NL];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) gw[l] = MFMA16(xa[a][b], xb[l][a][b], gw[l]);
+                for (int l = 0; l < NL; ++l) {
+                  f32x4v t4 = ga[0] * xb[l][0];
+#pragma unroll
+                  for (int a = 1; a < KT; ++a) t4 += ga[a] * xb[l][a];
+                  sl[l] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+                  sl[l] += __shfl_xor(sl[l], 16);
+                  sl[l] += __shfl_xor(sl[l], 32);
+                  gw[l][0] = quarter == pp ? sl[l] : gw[l][0];   // register 0 of quarter qu is out-edge it + qu
+                }
+              }
+            } else {
+              const int pa = p0 + min(it + 4 * (n & 3) + (n >> 2), m_out - 1);
+              const float* gta = g_tbw + (int64_t)pa * V + 4 * quarter;
+              f32x4v xa[KT];
+#pragma unroll
+              for (int a = 0; a < KT; ++a) xa[a] = *(const f32x4v*)(gta + 16 * a);
+#pragma unroll
+              for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+#pragma unroll
+                  for (int b = 0; b < 4; ++b) gw[l] = MFMA16(xa[a][b], xb[l][a][b], gw[l]);
+            }
             // park GW of this tile (lane-private LDS column; the chain below replaces it with the weights)
 #pragma unroll
             for (int l = 0; l < NL; ++l)
@@ -1898,23 +1928,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
             for (int l = 0; l < NL; ++l)
 #pragma unroll
               for (int r = 0; r < 4; ++r) gw[l][r] = wl[64 * ((t * NL + l) * 4 + r)];
-        // ---- scalar chain for this lane's 4 pairs (p = it + 4*quarter + r, q)
+        // ---- scalar chain for this lane's 4 pairs (p = it + 4 r + quarter, q); passes r whose four out-edges all lie
+        //      past the list are skipped (wave-uniform)
         float w[NL][4];
         float gpx[4], gpy[4], gpz[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pi = it + 4 * quarter + r;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) w[l][r] = 0.f;
+          gpx[r] = gpy[r] = gpz[r] = 0.f;
+          if (it + 4 * r >= m_out) continue;
+          const int pi = it + 4 * r + quarter;
           const int p = p0 + min(pi, m_out - 1);
           const bool ok = qv && pi < m_out && p != q;
           const float px = uvec_p[3 * (int64_t)p], py = uvec_p[3 * (int64_t)p + 1], pz = uvec_p[3 * (int64_t)p + 2];
-#if 0
-          {  // diagnostic: no per-pair scalar chain
-#pragma unroll
-            for (int l = 0; l < NL; ++l) w[l][r] = ok ? gw[l][r] * G[0] : 0.f;
-            gpx[r] = gpy[r] = gpz[r] = px * qx;
-            continue;
-          }
-#endif
           const float c = px * qx + py * qy + pz * qz;
           float y[4], dy[4], GY[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1943,8 +1970,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
         // g_up[p] += sum over the 16 in-edges of this tile (lanes n within each 16-lane row), one writer lane per row
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          if (it + 4 * r >= m_out) continue;
           const float sx = lcao_row16_sum(gpx[r]), sy = lcao_row16_sum(gpy[r]), sz = lcao_row16_sum(gpz[r]);
-          const int pi = it + 4 * quarter + r;
+          const int pi = it + 4 * r + quarter;
           if (n == 0 && pi < m_out) {
             float* o = g_up + 3 * (int64_t)(p0 + pi);
             o[0] += sx; o[1] += sy; o[2] += sz;
@@ -1973,22 +2001,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
 #pragma unroll
               for (int r = 0; r < 4; ++r) w[l][r] = wl[64 * ((t * NL + l) * 4 + r)];
         // ---- GEMM 2: gA[l][t] (channel row, in-edge n) += sum_p g_tbw[p][channel] w[l][p, q_n]
-        //      k-step r: quarter `quarter` contributes p = it + 4*quarter + r (B operand = w[l][r]).
+        //      k-step r: quarter `quarter` contributes p = it + 4 r + quarter (B operand = w[l][r]); k-steps past the list
+        //      are skipped.
         //      V >= 64: the A operand is read as float4 (channels 64h + 4n .. +3); its four floats feed the four channel
         //      tiles 4h + j, so tile 4h + j holds channels 64h + 4i + j in its rows i (a permuted tiling that the store
         //      below undoes) — 2 x 16-B loads per k-step instead of 8 x 4-B.
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pr = p0 + min(it + 4 * quarter + r, m_out - 1);
+          if (it + 4 * r >= m_out) continue;
+          const int pr = p0 + min(it + 4 * r + quarter, m_out - 1);
           if constexpr (V >= 64) {
             const float* gtr = g_tbw + (int64_t)pr * V + 4 * n;
-#if 0
-            {
-              const f32x4v av = *(const f32x4v*)(gtr);
-#pragma unroll
-              for (int l = 0; l < NL; ++l) gA[l][0] = MFMA16(av[0], w[l][r], gA[l][0]);
-            }
-#else
 #pragma unroll
             for (int h = 0; h < V / 64; ++h) {
               const f32x4v av = *(const f32x4v*)(gtr + 64 * h);
@@ -1997,7 +2020,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
 #pragma unroll
                 for (int l = 0; l < NL; ++l) gA[l][4 * h + j] = MFMA16(av[j], w[l][r], gA[l][4 * h + j]);
             }
-#endif
           } else {
             const float* gtr = g_tbw + (int64_t)pr * V + n;
 #pragma unroll

@@ -125,7 +125,7 @@ def randomise_bn(model, seed):
             m.bias.data.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
 
 
-def run_case(name, graph_dict, kwargs, seed=0, train=False, keep_triplets=False, dtypes=("f32", "f64")):
+def run_case(name, graph_dict, kwargs, seed=0, train=False, keep_triplets=False, dtypes=("f32", "f64"), drop=(), note=None):
     torch.manual_seed(seed)
     model = LCAONet(**kwargs)
     randomise_bn(model, seed + 1)
@@ -177,6 +177,10 @@ def run_case(name, graph_dict, kwargs, seed=0, train=False, keep_triplets=False,
         for k, v in cap.items():
             d[f"{tag}/{k}"] = v.numpy()
         model = m
+    for k in drop:      # keys that do not reproduce from run to run are not data: left out, with the reason recorded
+        d.pop(k)
+    if note is not None:
+        d["note"] = np.array(note)
     path = os.path.join(OUT, f"{name}.npz")
     np.savez_compressed(path, **d)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB  out={d['f32/out'].ravel()[:3]}")
@@ -210,7 +214,10 @@ def extra_cases():
     g1 = graph_to_dict(random_periodic_cells(2, 12, 6.0, 0.99 * 5.0, max_z=36, seed=7))
     run_case("cells_h16_tanh_autograd_forces", g1,
              dict(emb_size=16, emb_size_coeff=16, emb_size_conv=16, n_interaction=2, cutoff=5.0, activation="Tanh",
-                  regress_forces=True, direct_forces=False), 41)
+                  regress_forces=True, direct_forces=False), 41, drop=("f32/force",),
+             note="f32/force left out: the reference's own fp32 autograd forces differ by ~2 % between two runs of this "
+                  "script (its radial basis re-evaluates the envelope once per orbital; profiles/r02/"
+                  "reference_fp32_force_noise.txt) — forces are compared with f64/force")
 
 
 def main():

@@ -14,10 +14,10 @@ ctx = EdgeContext.build(g["edge_index"], N)
 V, NL = 128, 3
 gen = torch.Generator(device=dev).manual_seed(0)
 Ag = torch.randn(E, NL, V, device=dev, generator=gen)
-gram = torch.einsum("elv,emv->elm", Ag, Ag)
+gram = torch.einsum("elv,emv->elm", Ag.double(), Ag.double())
 iu = torch.triu_indices(4, 4)
-G = torch.zeros(E, 4, 4, device=dev); G[:, :NL, :NL] = gram
-gram10 = G[:, iu[0], iu[1]].contiguous()
+G = torch.zeros(E, 4, 4, device=dev); G[:, :NL, :NL] = torch.linalg.cholesky(gram).transpose(1, 2).float()   # R, R^T R = A A^T
+gram10 = G[:, iu[0], iu[1]].contiguous()            # the per-edge triangular factor the kernels read
 u = torch.nn.functional.normalize(torch.randn(E, 3, device=dev, generator=gen), dim=1)
 tbw = torch.empty(E, V, device=dev)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
