@@ -37,6 +37,7 @@ sys.path.insert(0, REPO)
 
 # MI355X ceilings (/opt/skills/guides/MI355X_MICROARCH.md: "Chip-level parameters")
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_16BIT_MFMA_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA ("~2.5 PF dense"; the 5 PF figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -173,6 +174,30 @@ def roofline_forward(model, n_nodes: int, n_edges: int, seconds_per_forward: flo
             "bytes_per_edge": round(byts, 1), "gemm_flop_per_edge": round(flop, 1),
             "hbm_frac": round(byts * n_edges / seconds_per_forward / (PEAK_HBM_GBS * 1e9), 4),
             "mfma_frac": round(flop * n_edges / seconds_per_forward / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)}
+
+
+def mode_roofline(fn, steps: int, work: dict, n_edges: int):
+    """Roofline block of a secondary mode: `fn()` (one step of the mode) runs `steps` times with every C-ABI call
+    bracketed by HIP events; the entry point with the largest total time is the mode's dominant kernel and is priced with
+    its ALGORITHMIC work per launch from `work` = {entry point: (bound, per-edge flop or bytes, peak, unit, note)}."""
+    from lcaonet_amd import ops
+
+    with ops.profile() as prof:
+        for _ in range(steps):
+            fn()
+        ks = prof.summary()
+    if not ks:
+        return None
+    known = {k: v for k, v in ks.items() if k in work}
+    name, (calls, ms) = max((known or ks).items(), key=lambda kv: kv[1][1])
+    out = {"kernel": name, "avg_launch_ms": round(ms / calls, 4), "launches_per_step": round(calls / steps, 2),
+           "share_of_bracketed_time": round(ms / sum(v[1] for v in ks.values()), 3)}
+    if name in work:
+        bound, per_edge, peak, unit, note = work[name]
+        rate = per_edge * n_edges / (ms / calls * 1e-3) / (1e12 if bound == "mfma" else 1e9)
+        out.update({"bound": bound, "achieved": round(rate, 1), "peak": peak, "unit": unit, "frac": round(rate / peak, 4),
+                    "traffic": None, "algorithmic_per_launch": per_edge * n_edges, "note": note})
+    return out
 
 
 def run_strong(args, model, gen_kw, rank, world, dev, barrier, reduce_times):
@@ -397,6 +422,25 @@ def main():
 
     secondary_error = None
     pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = ftrain_ms = mat_ms = mat_err = h_ms = h_err = None
+    roof_bf = roof_h = roof_forces = roof_train = roof_ftrain = None
+    D_, C_, V_, NL_ = model.elec_info.n_orb, model.emb_size_coeff, model.emb_size_conv, model.n_l
+    mlp_flop = 2.0 * D_ * (C_ * V_ + V_ * V_)
+    # algorithmic work per edge of the kernels that dominate the secondary modes
+    mode_work = {
+        "lcao_coeff_mlp_contract_f16": ("mfma", mlp_flop, PEAK_16BIT_MFMA_TFLOPS, "TFLOP/s",
+                                        "one v_mfma_f32_16x16x32_f16 per product; the kernel is VALU-issue bound: two "
+                                        "transcendentals per activation on a SIMD shared with the MFMA issue (DESIGN.md section 4)"),
+        "lcao_coeff_mlp_contract_bf16x3": ("mfma", mlp_flop, PEAK_16BIT_MFMA_TFLOPS, "TFLOP/s",
+                                           "algorithmic flop; three bf16 MFMAs are issued per product (3x this rate on the pipe)"),
+        # reverse of the three-body term: Ag, g_tbw, factor, unit vector read; g_Ag, g_gram, g_u written
+        "lcao_triplet_bwd_mfma": ("hbm", 8.0 * NL_ * V_ + 4.0 * V_ + 116.0, PEAK_HBM_GBS, "GB/s",
+                                  "degree-18 lists fill 16-wide MFMA tiles to 32 %: the kernel sits between its HBM and "
+                                  "matrix ceilings (DESIGN.md section 4)"),
+        "lcao_pair_contract_bwd": ("hbm", 4.0 * NL_ * V_ + 8.0 * V_ + 40.0 + 8.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
+        "lcao_pair_contract": ("hbm", 4.0 * (NL_ + 1) * V_ + 40.0 + 4.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
+        "lcao_triplet_gemm": ("hbm", 4.0 * NL_ * V_ + 52.0 + 4.0 * V_, PEAK_HBM_GBS, "GB/s", ""),
+        "lcao_wgrad": ("mfma", 2.0 * V_ * V_, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "dW = G^T X over the edge rows, per V x V weight"),
+    }
     kall = {}
     if rank == 0:
         try:
@@ -415,6 +459,9 @@ def main():
                 pair_ms, pair_err = timed(cst_mode="pair")                   # species-pair table
                 bf_ms, bf_err = timed(precision="bf16x3")                    # BASELINE config 3
                 h_ms, h_err = timed(precision="f16")                         # ... at its stated tolerance (1e-3)
+                with torch.no_grad():
+                    roof_bf = mode_roofline(lambda: model(batch, precision="bf16x3"), 3, mode_work, E)
+                    roof_h = mode_roofline(lambda: model(batch, precision="f16"), 3, mode_work, E)
                 bp_ms, bp_err = timed(precision="bf16x3", cst_mode="pair")
             if not with_forces and args.workload == "cfg2":
                 # rows f3 of SURVEY.md 8: energy + autograd forces (reverse sweep) and one full training step, same batch
@@ -427,6 +474,7 @@ def main():
                         fm(batch)
                     torch.cuda.synchronize()
                     forces_ms = 1e3 * (time.perf_counter() - t1) / max(args.steps // 2, 2)
+                    roof_forces = mode_roofline(lambda: fm(batch), 3, mode_work, E)
                 del fm
                 tm = build_model(model_kw, 1234, dev).train()
                 opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
@@ -444,8 +492,10 @@ def main():
                     train_step()
                 torch.cuda.synchronize()
                 train_ms = 1e3 * (time.perf_counter() - t1) / max(args.steps // 4, 2)
+                roof_train = mode_roofline(train_step, 2, mode_work, E)
                 del tm, opt
                 # training ON FORCES: energy + exact autograd forces (create_graph) + backward through the force graph
+                torch.cuda.reset_peak_memory_stats()
                 ftm = build_model(dict(model_kw, regress_forces=True, direct_forces=False), 1234, dev).train()
                 fopt = torch.optim.Adam(ftm.parameters(), lr=1e-4)
                 f_target = torch.zeros(N, 3, device=dev)
@@ -463,6 +513,8 @@ def main():
                     force_train_step()
                 torch.cuda.synchronize()
                 ftrain_ms = 1e3 * (time.perf_counter() - t1) / 2
+                roof_ftrain = mode_roofline(force_train_step, 1, mode_work, E)
+                ftrain_peak_gib = torch.cuda.max_memory_allocated() / 2**30
                 del ftm, fopt
                 torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
@@ -475,6 +527,9 @@ def main():
         # (SURVEY.md §8d row "f_coeffs"): 2*D*(C*V + V*V) flop per edge; HBM 4*D*C read + 4*(n_l+1)*V write per edge.
         name = "lcao_coeff_mlp_contract"
         roof = None
+        if with_forces:   # force workloads (cfg5): the dominant kernel of the energy + forces step, priced like the secondary modes
+            with torch.no_grad():
+                roof = mode_roofline(lambda: model(batch, fused=fused, **mkw), 2, mode_work, E)
         if name in ksum:
             calls, ms = ksum[name]
             per_launch_ms = ms / calls
@@ -564,7 +619,7 @@ def main():
                     "bf16 MFMA, each fp32 operand split into two bf16 terms (3 MFMAs per product, fp32 accumulate); "
                     "general per-edge cst", "dtype": "bf16x3",
             "ms_per_step_rank0": round(bf_ms, 3), "edges_per_s_rank0": E / (bf_ms * 1e-3),
-            "max_rel_diff_vs_fp32_output": bf_err,
+            "max_rel_diff_vs_fp32_output": bf_err, "roofline": roof_bf,
             "with_pair_table": None if bp_ms is None else {
                 "ms_per_step_rank0": round(bp_ms, 3), "edges_per_s_rank0": E / (bp_ms * 1e-3),
                 "max_rel_diff_vs_fp32_output": bp_err}}
@@ -573,22 +628,23 @@ def main():
                 "note": "NOT the headline: BASELINE config 3 at its stated tolerance (1e-3) — the per-edge GEMMs with operands rounded "
                         "once to fp16, ONE v_mfma_f32_16x16x32_f16 per product, fp32 accumulation; general per-edge cst",
                 "dtype": "f16", "ms_per_step_rank0": round(h_ms, 3), "edges_per_s_rank0": E / (h_ms * 1e-3),
-                "max_rel_diff_vs_fp32_output": h_err}
+                "max_rel_diff_vs_fp32_output": h_err, "roofline": roof_h}
         if forces_ms is not None:
             line["autograd_forces_mode"] = {
                 "note": "NOT the headline: regress_forces=True, direct_forces=False — energy and F = -dE/dpos by the HIP reverse "
                         "sweep (species-pair forward)", "ms_per_step_rank0": round(forces_ms, 3),
-                "edges_per_s_rank0": E / (forces_ms * 1e-3)}
+                "edges_per_s_rank0": E / (forces_ms * 1e-3), "roofline": roof_forces}
         if train_ms is not None:
             line["training_step_mode"] = {
                 "note": "NOT the headline: train mode, forward + HIP backward (all parameter gradients) + Adam step",
-                "ms_per_step_rank0": round(train_ms, 3), "edges_per_s_rank0": E / (train_ms * 1e-3)}
+                "ms_per_step_rank0": round(train_ms, 3), "edges_per_s_rank0": E / (train_ms * 1e-3), "roofline": roof_train}
         if ftrain_ms is not None:
             line["force_training_step_mode"] = {
                 "note": "NOT the headline: train mode, regress_forces=True, direct_forces=False — energy, exact autograd forces "
                         "(create_graph), L1 loss on both, backward through the force graph (twice-differentiable HIP "
                         "primitives, model/double.py) + Adam step",
-                "ms_per_step_rank0": round(ftrain_ms, 3), "edges_per_s_rank0": E / (ftrain_ms * 1e-3)}
+                "ms_per_step_rank0": round(ftrain_ms, 3), "edges_per_s_rank0": E / (ftrain_ms * 1e-3),
+                "peak_memory_GiB": round(ftrain_peak_gib, 1), "roofline": roof_ftrain}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -30,6 +30,19 @@ static inline unsigned lcao_blocks(int64_t n, int per_block, int64_t cap = (int6
   return unsigned(b);
 }
 
+// Zero-fill as a KERNEL launch.  The library issues no hipMemsetAsync: inside a captured HIP graph a memset NODE faulted on
+// replay ("Memory access fault by GPU") as soon as the process had mapped a new allocator segment after the capture
+// (profiles/r03/tile_queue_suspects.txt, ROCm 7.2); kernel nodes do not.
+static __global__ void k_lcao_zero_words(uint32_t* __restrict__ p, int64_t n_words) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline int lcao_zero_async(void* p, size_t bytes, hipStream_t st) {   // bytes % 4 == 0
+  if (bytes == 0) return LCAO_OK;
+  const int64_t n_words = (int64_t)(bytes / 4);
+  hipLaunchKernelGGL(k_lcao_zero_words, dim3(lcao_blocks(n_words, 256, 4096)), dim3(256), 0, st, (uint32_t*)p, n_words);
+  return lcao_launch_status();
+}
+
 __device__ __forceinline__ float lcao_silu(float x) {
   // x * sigmoid(x) in 5 VALU ops: v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul (each transcendental <= 1 ulp).
   // A plain `x / (1 + expf(-x))` compiles to the 10+-instruction IEEE division sequence (v_div_scale/fmas/fixup),

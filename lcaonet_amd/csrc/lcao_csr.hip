@@ -103,9 +103,9 @@ extern "C" int lcao_build_csr(const int64_t* idx_s, const int64_t* idx_t, int64_
   LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(in_ptr);
   hipStream_t st = (hipStream_t)stream;
   if (n_edges == 0) {
-    hipError_t e1 = hipMemsetAsync(out_ptr, 0, (size_t)(n_nodes + 1) * 4, st);
-    hipError_t e2 = hipMemsetAsync(in_ptr, 0, (size_t)(n_nodes + 1) * 4, st);
-    return e1 != hipSuccess ? int(e1) : (e2 != hipSuccess ? int(e2) : LCAO_OK);
+    const int e1 = lcao_zero_async(out_ptr, (size_t)(n_nodes + 1) * 4, st);
+    const int e2 = lcao_zero_async(in_ptr, (size_t)(n_nodes + 1) * 4, st);
+    return e1 != LCAO_OK ? e1 : e2;
   }
   LCAO_CHECK_PTR(idx_s); LCAO_CHECK_PTR(idx_t); LCAO_CHECK_PTR(order); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p);
   LCAO_CHECK_PTR(in_pos); LCAO_CHECK_PTR(src_o); LCAO_CHECK_PTR(dst_o); LCAO_CHECK_PTR(workspace);

@@ -955,8 +955,7 @@ static int edge_node_message_agg_lowp(const float* bw, const float* Ps, const fl
   LCAO_CHECK_PTR(agg); LCAO_CHECK_PTR(out_ptr);
   hipStream_t st = (hipStream_t)stream;
   if (n_edges == 0) {
-    hipError_t me = hipMemsetAsync(agg, 0, sizeof(float) * (size_t)n_nodes * V, st);
-    return me == hipSuccess ? LCAO_OK : int(me);
+    return lcao_zero_async(agg, sizeof(float) * (size_t)n_nodes * V, st);
   }
   LCAO_CHECK_PTR(msg);
   // uneven degrees: message rows, then the per-node sum (both return at once when the hint reads 1)

@@ -132,6 +132,9 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ wl, int ldw
 // the last of `total_waves` re-arms the queue, so the words are zero again when the kernel ends.  Launches that share a
 // workspace must be ordered (same stream).
 __device__ __forceinline__ void lcao_tile_queue_leave(unsigned* q, unsigned total_waves) {
+#ifdef LCAO_DIAG_MEMSET_REARM   // diagnostic build (tools/probes/tile_queue_suspects.py): round 2's memset node instead, see launch
+  return;
+#endif
   if (atomicAdd(q + 1, 1u) == total_waves - 1) {
     atomicExch(q, 0u);
     atomicExch(q + 1, 0u);

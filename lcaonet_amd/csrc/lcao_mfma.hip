@@ -191,8 +191,8 @@ __global__ __launch_bounds__(THREADS) void k_coeff_mlp(const float* __restrict__
   }
   // Dynamic tile queue: the first tile of a wave is static, every further one is drawn from a device-scope
   // counter.  The queue re-arms ITSELF (lcao_tile_queue_leave: the last wave to leave zeroes it), so a launch needs no
-  // memset before it: hipMemsetAsync nodes in a captured HIP graph proved unreliable for this (profiles/r02/
-  // graph_replay_tile_queue.txt: replays at sizes with dynamic tiles lost them or faulted; static striding never did).  With a static split the two waves that share a SIMD finished 1.5 ms apart
+  // memset before it: a hipMemsetAsync NODE in a captured HIP graph faults on replay once a new allocator segment has been
+  // mapped (profiles/r03/tile_queue_suspects.txt; the library issues none, lcao_common.h: lcao_zero_async).  With a static split the two waves that share a SIMD finished 1.5 ms apart
   // (the older wave wins MFMA arbitration, completes its share early and leaves the other to run alone);
   // drawing tiles keeps both resident until the queue is empty.  Every wave exits once it draws tile >= n_tiles.
 #if LCAO_ABL & 16
@@ -374,6 +374,9 @@ static int launch_coeff_mlp_t(const float* cst, const float* rb, const int32_t* 
   static int k2_static = -1;
   if (k2_static < 0) { const char* e_ = getenv("LCAO_K2_STATIC"); k2_static = (e_ && atoi(e_)) ? 1 : 0; }
   if (k2_static) counter = nullptr;   // diagnostic: static striding, no queue
+#ifdef LCAO_DIAG_MEMSET_REARM   // diagnostic build only: the queue re-armed by a memset in front of the launch (a memset NODE in a capture)
+  if (counter && hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), st) != hipSuccess) return LCAO_ERR_INVALID;
+#endif
   hipLaunchKernelGGL((k_coeff_mlp<C, V, NL, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, st, cst, rb, order,
                      cst_row, l_of_d, wmul, W1, W2, E, D, accumulate, A, Bout, gate, src_p, Ag, gram, counter, g_clock_probe);
   return lcao_launch_status();
@@ -967,8 +970,8 @@ static int launch_edge_node_message_agg(const float* bw, const float* Ps, const 
   if (n_nodes == 0) return LCAO_OK;
   LCAO_CHECK_PTR(agg);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t me = hipMemsetAsync(agg, 0, sizeof(float) * (size_t)n_nodes * V, st);   // nodes without edges stay zero
-  if (me != hipSuccess) return int(me);
+  const int me = lcao_zero_async(agg, sizeof(float) * (size_t)n_nodes * V, st);   // nodes without edges stay zero
+  if (me != LCAO_OK) return me;
   if (n_edges == 0) return LCAO_OK;
   LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p);
   LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(Wn2); LCAO_CHECK_PTR(bn2);
@@ -2213,8 +2216,7 @@ extern "C" int lcao_wgrad(const float* G, const float* X, int64_t n_rows, int M,
   LCAO_CHECK_PTR(dW);
   hipStream_t st = (hipStream_t)stream;
   if (n_rows == 0) {
-    hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * M * K, st);
-    return e == hipSuccess ? LCAO_OK : int(e);
+    return lcao_zero_async(dW, sizeof(float) * M * K, st);
   }
   LCAO_CHECK_PTR(G); LCAO_CHECK_PTR(X); LCAO_CHECK_PTR(workspace);
   if (((uintptr_t)G | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) % 16) return LCAO_ERR_INVALID;
