@@ -188,10 +188,12 @@ def mode_roofline(fn, steps: int, work: dict, n_edges: int):
         ks = prof.summary()
     if not ks:
         return None
-    known = {k: v for k, v in ks.items() if k in work}
-    name, (calls, ms) = max((known or ks).items(), key=lambda kv: kv[1][1])
+    name, (calls, ms) = max(ks.items(), key=lambda kv: kv[1][1])
+    total = sum(v[1] for v in ks.values())
     out = {"kernel": name, "avg_launch_ms": round(ms / calls, 4), "launches_per_step": round(calls / steps, 2),
-           "share_of_bracketed_time": round(ms / sum(v[1] for v in ks.values()), 3)}
+           "share_of_bracketed_time": round(ms / total, 3),
+           "c_abi_ms_per_step": round(total / steps, 3), "c_abi_launches_per_step": round(sum(v[0] for v in ks.values()) / steps, 1),
+           "top_entry_points_ms_per_step": {k: round(v[1] / steps, 3) for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1])[:4]}}
     if name in work:
         bound, per_edge, peak, unit, note = work[name]
         rate = per_edge * n_edges / (ms / calls * 1e-3) / (1e12 if bound == "mfma" else 1e9)
@@ -439,7 +441,6 @@ def main():
         "lcao_pair_contract_bwd": ("hbm", 4.0 * NL_ * V_ + 8.0 * V_ + 40.0 + 8.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
         "lcao_pair_contract": ("hbm", 4.0 * (NL_ + 1) * V_ + 40.0 + 4.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
         "lcao_triplet_gemm": ("hbm", 4.0 * NL_ * V_ + 52.0 + 4.0 * V_, PEAK_HBM_GBS, "GB/s", ""),
-        "lcao_wgrad": ("mfma", 2.0 * V_ * V_, PEAK_F32_MFMA_TFLOPS, "TFLOP/s", "dW = G^T X over the edge rows, per V x V weight"),
     }
     kall = {}
     if rank == 0:

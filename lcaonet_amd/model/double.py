@@ -32,6 +32,26 @@ from ..data.keys import GraphKeys
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The force pass, torch.autograd.grad(E, pos, create_graph=True), wants dE/dpos only.  The engine prunes whole nodes that
+# do not lead to `pos`, but a custom Function that IS on the path is asked for all its input gradients (its
+# needs_input_grad reflects requires_grad, not the pruning): every Dense on the path would also form dE/dW (a wgrad over
+# the edge rows) and the orbital contraction dE/dT, only for the engine to drop them.  Inside `positions_only()` the
+# first-level backwards skip the gradients of inputs that are functions of the parameters alone.
+# ---------------------------------------------------------------------------------------------------------------------
+_POS_ONLY = False
+
+
+class positions_only:
+    def __enter__(self):
+        global _POS_ONLY
+        self.prev, _POS_ONLY = _POS_ONLY, True
+
+    def __exit__(self, *exc):
+        global _POS_ONLY
+        _POS_ONLY = self.prev
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # dense <-> wgrad
 # ---------------------------------------------------------------------------------------------------------------------
 class _DenseFn(Function):
@@ -46,8 +66,8 @@ class _DenseFn(Function):
         x, W = ctx.saved_tensors
         g = g.contiguous()
         gx = dense(g, W.t()) if ctx.needs_input_grad[0] else None
-        gW = wgrad(g, x) if ctx.needs_input_grad[1] else None
-        gb = g.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        gW = wgrad(g, x) if (ctx.needs_input_grad[1] and not _POS_ONLY) else None      # weights: parameters only
+        gb = g.sum(0) if (ctx.has_b and ctx.needs_input_grad[2] and not _POS_ONLY) else None
         return gx, gW, gb
 
 
@@ -259,7 +279,7 @@ class _ContractFn(Function):
         rb, T = ctx.saved_tensors
         g = g.contiguous()
         return (_ContractDrbFn.apply(g, T, ctx.geo) if ctx.needs_input_grad[0] else None,
-                _ContractDtFn.apply(g, rb, ctx.geo) if ctx.needs_input_grad[1] else None, None)
+                _ContractDtFn.apply(g, rb, ctx.geo) if (ctx.needs_input_grad[1] and not _POS_ONLY) else None, None)  # T: parameters only
 
 
 class _ContractDrbFn(Function):
@@ -677,7 +697,8 @@ def forward_exact_forces(model, graph, update_stats: bool = True, tables=None):
     with torch.enable_grad():
         pos = graph[GraphKeys.Pos].detach().float().requires_grad_(True)
         out = energy(model, graph, pos, x_tab, cst_pair)
-        forces = [-torch.autograd.grad(out[:, i].sum(), pos, create_graph=True)[0] for i in range(model.out_size)]
+        with positions_only():
+            forces = [-torch.autograd.grad(out[:, i].sum(), pos, create_graph=True)[0] for i in range(model.out_size)]
     force = forces[0] if model.out_size == 1 else torch.stack(forces, dim=1)
     return out, force
 
