@@ -133,11 +133,11 @@ def cpu_baseline(max_seconds: float = 30.0) -> dict:
     return out
 
 
-PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03", "pmc_traffic.json")
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02/pmc_traffic.json: separate FETCH_SIZE /
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03/pmc_traffic.json: separate FETCH_SIZE /
     WRITE_SIZE passes of this same workload, gfx950 x2 read correction), or None.  NOT measured in this run: the file
     carries the commit and date of its passes, repeated in the line as `traffic_source`."""
     try:
