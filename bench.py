@@ -436,8 +436,8 @@ def main():
                                            "algorithmic flop; three bf16 MFMAs are issued per product (3x this rate on the pipe)"),
         # reverse of the three-body term: Ag, g_tbw, factor, unit vector read; g_Ag, g_gram, g_u written
         "lcao_triplet_bwd_mfma": ("hbm", 8.0 * NL_ * V_ + 4.0 * V_ + 116.0, PEAK_HBM_GBS, "GB/s",
-                                  "degree-18 lists fill 16-wide MFMA tiles to 32 %: the kernel sits between its HBM and "
-                                  "matrix ceilings (DESIGN.md section 4)"),
+                                  "in- and out-edge lists are cut into 16-wide MFMA tiles (a degree-18 list fills them to 32 %): "
+                                  "the kernel sits between its HBM and matrix ceilings (DESIGN.md section 4)"),
         "lcao_pair_contract_bwd": ("hbm", 4.0 * NL_ * V_ + 8.0 * V_ + 40.0 + 8.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
         "lcao_pair_contract": ("hbm", 4.0 * (NL_ + 1) * V_ + 40.0 + 4.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
         "lcao_triplet_gemm": ("hbm", 4.0 * NL_ * V_ + 52.0 + 4.0 * V_, PEAK_HBM_GBS, "GB/s", ""),

@@ -188,8 +188,11 @@ int lcao_triplet_literal(const float* cstf, const float* rb, const float* shb, c
  * LCAOEmbedding and cst_row[p] = z_s * zdim + z_t, so the (E, D, C) tensor is never materialised; every (edge, orbital)
  * row still runs through both layers).
  * Outputs (p-space): B (E,V) [, Bv (E,V) with valence];  and EITHER the raw A (E,n_l,V) (Ag == NULL)
- * OR, for lcao_triplet_gemm, the gated copy Ag[p,l,:] = A[p,l,:] * gate[src_p[p],:] plus the per-edge Gram
- * matrix gram[p, 10] (upper triangle of A A^T over l, l' <= 3, row-major; ungated).  A is scratch when valence. */
+ * OR, for lcao_triplet_gemm, the gated copy Ag[p,l,:] = A[p,l,:] * gate[src_p[p],:] plus the per-edge TRIANGULAR
+ * FACTOR gram[p, 10]: R upper triangular over l, l' <= 3 (row-major upper triangle, zero beyond n_l) with R^T R = A A^T of
+ * the ungated A, from a modified Gram-Schmidt sweep over the vectors — |sum_l y_l A_l|^2 = |R y|^2 is then a sum of
+ * squares (the Gram form y^T (A A^T) y of ABI 1 lost a factor S/|v| of accuracy for correlated A_l).  The argument keeps
+ * its name; every consumer below reads the factor.  A is scratch when valence. */
 int lcao_coeff_mlp_contract(const float* cst, const float* rb, const int32_t* order, const int32_t* cst_row,
                             const int32_t* l_of_d, const float* valence_ed /* (E,D) orig order, nullable */, const float* W1,
                             const float* W2, const float* gate /* (N,V) sigmoid(xk), nullable */,
@@ -263,7 +266,7 @@ int lcao_edge_node_message_agg_f16(const float* bw, const float* Ps, const float
 
 /* Species-pair form of lcaonet.py:170-183,200 (eval mode, no valence): with
  * Tf[(z_s*zdim + z_t), d, :] = f_coeffs(cst(z_s, z_t))[d, :] precomputed on the (zdim^2, D, V) pair table,
- *   A[p,l,:] = sum_{d in l} rb[e,d] * Tf[pair(p),d,:];  writes Ag = A * gate[src_p], B = sum_l A, gram = A A^T
+ *   A[p,l,:] = sum_{d in l} rb[e,d] * Tf[pair(p),d,:];  writes Ag = A * gate[src_p], B = sum_l A, gram = the triangular factor R (R^T R = A A^T, as above)
  * exactly as lcao_coeff_mlp_contract does (same consumers), without the 2*D*(C*V+V*V) flop per edge. */
 int lcao_pair_contract(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d, const int64_t* z,
                        const int32_t* src_p, const int32_t* dst_p, const float* gate, int64_t n_edges, int n_orb, int V,
@@ -345,7 +348,9 @@ int lcao_message_bwd_fused(const float* g_agg, const int32_t* src_p, const int32
                            int V, float* g_bw, float* g_pre1, float* g_pre2, void* stream);
 int lcao_lcao_weight_bwd_fused(const float* g_bw, const float* B, const float* ft, const float* WbT, const float* W3T,
                                int64_t n_edges, int V, float* g_B, float* g_tbw, float* g_ft, void* stream);
-/* three-body backward: g_tbw -> g_Ag, g_gram (per in-edge), g_uq / g_up (dE/d unit vector as in-edge / out-edge);
+/* three-body backward: g_tbw -> g_Ag, g_gram (per in-edge: dE/d(A A^T), upper triangle with doubled off-diagonals — the
+ * GRADIENT stays in Gram coordinates, lcao_pair_contract_bwd turns it into dE/dA; `gram` IN is the triangular factor),
+ * g_uq / g_up (dE/d unit vector as in-edge / out-edge);
  * tbase[s] = offset of node s in the (sum_s m_in*m_out) float scratch `gc_scratch` */
 int lcao_triplet_bwd(const float* g_tbw, const float* Ag, const float* gram, const float* uvec_p, const int32_t* src_p,
                      const int32_t* dst_p, const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr,
