@@ -1291,3 +1291,28 @@ def test_training_step_is_bitwise_reproducible(dev, mode):
         assert len(again) == len(ref)
         for a, b in zip(ref, again):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16", "bf16x3"])
+def test_lowp_pack_rows_is_bit_exact(dev, precision):
+    """lcao_lowp_pack_rows (round 3): the MFMA operands of the 16-bit coefficient kernels are byte work — per 8 values 16
+    bytes of fp16 (round to nearest even), or 8 bf16 high terms then 8 bf16 low terms x - float(hi): equal, bit for bit,
+    to the same roundings done by torch; ragged row counts, zeros, subnormal-range and large values included."""
+    from lcaonet_amd import ops
+    gen = torch.Generator().manual_seed(17)
+    for rows, width in ((1, 32), (37, 64), (1369 * 8, 128)):
+        x = torch.randn(rows, width, generator=gen) * torch.tensor(10.0) ** torch.randint(-9, 5, (rows, 1), generator=gen).float()
+        x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, 1e-8, 3.0e-5, -7.5])
+        packed = ops.lowp_pack_rows(x.to(dev), precision).cpu()
+        groups = x.reshape(-1, 8)
+        if precision == "f16":
+            want = groups.to(torch.float16).view(torch.uint8).reshape(-1)
+        else:
+            hi = groups.to(torch.bfloat16)
+            lo = (groups - hi.float()).to(torch.bfloat16)
+            want = torch.cat([hi.view(torch.uint8).reshape(-1, 16), lo.view(torch.uint8).reshape(-1, 16)], dim=1).reshape(-1)
+        assert packed.numel() == want.numel()
+        assert torch.equal(packed, want)
+    with pytest.raises(ValueError):
+        ops.lowp_pack_rows(torch.zeros(4, 24, device=dev), precision)     # rows must be a multiple of 32 values wide
