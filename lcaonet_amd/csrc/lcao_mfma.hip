@@ -1821,6 +1821,179 @@ __global__ __launch_bounds__(256) void k_triplet_bwd_mfma(
 #ifndef LCAO_TBWD_WAVES
 #define LCAO_TBWD_WAVES 2
 #endif
+// A SHORT in-edge tile (its in-edges x n_l fit 16 MFMA columns: the 2 left over from a degree-18 list) with the pair
+// (in-edge q, l) on the MFMA column instead of q alone: both GEMMs then take V / 16 x 4 MFMAs per out-tile instead of
+// n_l x that, for the same result (a full tile spends its 16 columns on 16 in-edges; this one had 2 of them valid).
+// Lane (column j, quarter): q = in-edge j / NL of the tile, l = j % NL.  GEMM 1 leaves gw[r] = g_tbw[p] . Ag[q, l] for
+// p = it + 4 r + quarter; the chain of a pair needs the n_l values of its in-edge, which sit in n_l neighbouring lanes
+// (gathered by ds_bpermute); every one of those lanes runs the chain, the lane with l = 0 alone adds to the per-edge sums.
+template <int V, int NL, int NITC>
+__device__ __forceinline__ void tbwd_short_in_tile(
+    const float* __restrict__ g_tbw, const float* __restrict__ Ag, const float* __restrict__ gram,
+    const float* __restrict__ uvec_p, const int32_t* __restrict__ in_pos, int j0, int jt, int m_in, int p0, int m_out,
+    float* __restrict__ wl, float* __restrict__ g_Ag, float* __restrict__ g_gram, float* __restrict__ g_uq,
+    float* __restrict__ g_up) {
+  constexpr int KT = V / 16;
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 15, quarter = lane >> 4;
+  const int qi = n / NL, lm = n - qi * NL;                 // this column's in-edge (within the tile) and l
+  const bool qv = (jt + qi) < m_in && qi * NL + lm < 16;
+  const int q = in_pos[j0 + (qv ? jt + qi : 0)];
+  const float qx = uvec_p[3 * (int64_t)q], qy = uvec_p[3 * (int64_t)q + 1], qz = uvec_p[3 * (int64_t)q + 2];
+  float G[10], gG[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { G[i] = gram[(int64_t)q * 10 + i]; gG[i] = 0.f; }
+  float gqx = 0.f, gqy = 0.f, gqz = 0.f;
+  const float* agq = Ag + ((int64_t)q * NL + lm) * V + 4 * quarter;
+  const int lane_l0 = (lane & 48) + qi * NL;               // lane holding l = 0 of this in-edge (same quarter)
+  for (int ic = 0; ic < m_out; ic += 16 * NITC) {
+    asm volatile("" ::: "memory");
+    const int nit = min(NITC, (m_out - ic + 15) >> 4);
+    {  // ---- phase A1: GEMM 1, one accumulator per out-tile
+      f32x4v xb[KT];
+#pragma unroll
+      for (int a = 0; a < KT; ++a) xb[a] = *(const f32x4v*)(agq + 16 * a);
+      for (int t = 0; t < nit; ++t) {
+        asm volatile("" ::: "memory");
+        const int it = ic + 16 * t;
+        f32x4v gw = f32x4v{0.f, 0.f, 0.f, 0.f};
+        const int rem = m_out - it;
+        if (rem <= 4) {
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) {
+            if (pp >= rem) break;
+            const float* gtp = g_tbw + (int64_t)(p0 + it + pp) * V + 4 * quarter;
+            f32x4v t4 = *(const f32x4v*)(gtp) * xb[0];
+#pragma unroll
+            for (int a = 1; a < KT; ++a) t4 += *(const f32x4v*)(gtp + 16 * a) * xb[a];
+            float sl = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+            sl += __shfl_xor(sl, 16);
+            sl += __shfl_xor(sl, 32);
+            gw[0] = quarter == pp ? sl : gw[0];
+          }
+        } else {
+          const int pa = p0 + min(it + 4 * (n & 3) + (n >> 2), m_out - 1);
+          const float* gta = g_tbw + (int64_t)pa * V + 4 * quarter;
+          f32x4v xa[KT];
+#pragma unroll
+          for (int a = 0; a < KT; ++a) xa[a] = *(const f32x4v*)(gta + 16 * a);
+#pragma unroll
+          for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) gw = MFMA16(xa[a][b], xb[a][b], gw);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wl[64 * (t * 4 + r)] = gw[r];
+      }
+    }
+    asm volatile("" ::: "memory");
+    // ---- phase A2: the scalar chain; the n_l GW values of an in-edge come from its n_l lanes
+    for (int t = 0; t < nit; ++t) {
+      asm volatile("" ::: "memory");
+      const int it = ic + 16 * t;
+      float w[4], gpx[4], gpy[4], gpz[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        w[r] = 0.f;
+        gpx[r] = gpy[r] = gpz[r] = 0.f;
+        if (it + 4 * r >= m_out) continue;
+        const float mine = wl[64 * (t * 4 + r)];
+        float gwl[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) gwl[l] = __shfl(mine, lane_l0 + l);
+        const int pi = it + 4 * r + quarter;
+        const int p = p0 + min(pi, m_out - 1);
+        const bool ok = qv && pi < m_out && p != q;
+        const float px = uvec_p[3 * (int64_t)p], py = uvec_p[3 * (int64_t)p + 1], pz = uvec_p[3 * (int64_t)p + 2];
+        const float c = px * qx + py * qy + pz * qz;
+        float y[4], dy[4], GY[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) { y[l] = l < NL ? lcao_y_l0(c, l) : 0.f; dy[l] = l < NL ? lcao_y_l0_grad(c, l) : 0.f; }
+        const float m = lcao_factor_quadratic<NL>(G, y, GY);
+        const float mc = fmaxf(m, 0.f);
+        const bool live = mc > 1e-24f;
+        const float inv = live ? __builtin_amdgcn_rsqf(mc) : 1e12f;
+        float g_inv = 0.f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) g_inv += gwl[l] * y[l];
+        const bool first = ok && lm == 0;                   // one lane per (p, q) pair feeds the per-edge / per-pair sums
+        const float g_m = (first && live) ? -0.5f * g_inv * inv * inv * inv : 0.f;
+        float gcv = 0.f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) gcv += (gwl[l] * inv + 2.0f * g_m * GY[l]) * dy[l];
+        gcv = first ? gcv : 0.f;
+        float ysel = y[0];
+#pragma unroll
+        for (int l = 1; l < NL; ++l) ysel = lm == l ? y[l] : ysel;
+        w[r] = ok ? ysel * inv : 0.f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int l2 = l; l2 < NL; ++l2) gG[gram_idx(l, l2)] += g_m * (l == l2 ? y[l] * y[l] : 2.0f * y[l] * y[l2]);
+        gqx += gcv * px; gqy += gcv * py; gqz += gcv * pz;
+        gpx[r] = gcv * qx; gpy[r] = gcv * qy; gpz[r] = gcv * qz;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (it + 4 * r >= m_out) continue;
+        const float sx = lcao_row16_sum(gpx[r]), sy = lcao_row16_sum(gpy[r]), sz = lcao_row16_sum(gpz[r]);
+        const int pi = it + 4 * r + quarter;
+        if (n == 0 && pi < m_out) {
+          float* o = g_up + 3 * (int64_t)(p0 + pi);
+          o[0] += sx; o[1] += sy; o[2] += sz;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wl[64 * (t * 4 + r)] = w[r];
+    }
+    asm volatile("" ::: "memory");
+    {  // ---- phase B: GEMM 2 with the weights of this column's (in-edge, l)
+      f32x4v gA[KT];
+#pragma unroll
+      for (int t2 = 0; t2 < KT; ++t2) gA[t2] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < nit; ++t) {
+        asm volatile("" ::: "memory");
+        const int it = ic + 16 * t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (it + 4 * r >= m_out) continue;
+          const float wr = wl[64 * (t * 4 + r)];
+          const int pr = p0 + min(it + 4 * r + quarter, m_out - 1);
+          const float* gtr = g_tbw + (int64_t)pr * V + 4 * n;
+#pragma unroll
+          for (int h = 0; h < V / 64; ++h) {
+            const f32x4v av = *(const f32x4v*)(gtr + 64 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gA[4 * h + j] = MFMA16(av[j], wr, gA[4 * h + j]);
+          }
+        }
+      }
+      if (qv) {
+        float* go = g_Ag + ((int64_t)q * NL + lm) * V + 16 * quarter;
+#pragma unroll
+        for (int h = 0; h < V / 64; ++h)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            f32x4v v = f32x4v{gA[4 * h][rr], gA[4 * h + 1][rr], gA[4 * h + 2][rr], gA[4 * h + 3][rr]};
+            float* dst = go + 64 * h + 4 * rr;
+            if (ic > 0) v += *(const f32x4v*)dst;
+            *(f32x4v*)dst = v;
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { gG[i] += __shfl_xor(gG[i], 16); gG[i] += __shfl_xor(gG[i], 32); }
+  gqx += __shfl_xor(gqx, 16); gqx += __shfl_xor(gqx, 32);
+  gqy += __shfl_xor(gqy, 16); gqy += __shfl_xor(gqy, 32);
+  gqz += __shfl_xor(gqz, 16); gqz += __shfl_xor(gqz, 32);
+  if (qv && quarter == 0 && lm == 0) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) g_gram[(int64_t)q * 10 + i] = gG[i];
+    g_uq[3 * (int64_t)q] = gqx; g_uq[3 * (int64_t)q + 1] = gqy; g_uq[3 * (int64_t)q + 2] = gqz;
+  }
+}
+
 template <int V, int NL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_WAVES, LCAO_TBWD_WAVES))) void k_triplet_bwd_split(
     const float* __restrict__ g_tbw, const float* __restrict__ Ag, const float* __restrict__ gram,
@@ -1847,6 +2020,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
         }
       }
     for (int jt = 0; jt < m_in; jt += 16) {
+      if (NL > 1 && (m_in - jt) * NL <= 16) {   // wave-uniform: a short last tile, (in-edge, l) pairs on the MFMA columns
+        tbwd_short_in_tile<V, NL, NITC>(g_tbw, Ag, gram, uvec_p, in_pos, j0, jt, m_in, p0, m_out, wl, g_Ag, g_gram, g_uq, g_up);
+        continue;
+      }
       const bool qv = (jt + n) < m_in;
       const int q = in_pos[j0 + (qv ? jt + n : 0)];
       const float qx = uvec_p[3 * (int64_t)q], qy = uvec_p[3 * (int64_t)q + 1], qz = uvec_p[3 * (int64_t)q + 2];

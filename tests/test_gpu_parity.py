@@ -1316,3 +1316,46 @@ def test_lowp_pack_rows_is_bit_exact(dev, precision):
         assert torch.equal(packed, want)
     with pytest.raises(ValueError):
         ops.lowp_pack_rows(torch.zeros(4, 24, device=dev), precision)     # rows must be a multiple of 32 values wide
+
+
+@pytest.mark.gpu
+def test_index_checks_cover_forces_training_and_captures(dev):
+    """an atomic number above max_z must be flagged on EVERY entry point, not only the energy path of the
+    inference pipeline — the reverse-sweep forces, the differentiable (training) forward, and a CapturedForward (whose z is
+    fixed for its life: it raises at construction).  `model.strict_indices = True` raises before the call returns."""
+    from lcaonet_amd import _lib, ops
+    from lcaonet_amd.data.graph import Data
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import CapturedForward
+
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=1, cutoff=4.0, max_z=10)
+    good = random_periodic_cells(2, 8, 6.0, 0.99 * 4.0, seed=2, max_z=10).to(dev)
+    bad = Data(**{**good.to_dict(), "z": good["z"].clone()})
+    bad["z"][3] = 11
+    ops.raise_pending_errors(sync=True)
+
+    fm, _ = _random_model(dev, 2, regress_forces=True, direct_forces=False, **kw)       # forces by the reverse sweep
+    out, force = fm(bad)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(force).all())       # clamped: nothing read out of bounds
+    with pytest.raises(_lib.LcaoHipError, match="atomic number"):
+        ops.raise_pending_errors(sync=True)
+
+    tm, _ = _random_model(dev, 3, grad=True, **kw)                                      # differentiable forward
+    tm.train()
+    tm(bad).sum().backward()
+    with pytest.raises(_lib.LcaoHipError, match="atomic number"):
+        ops.raise_pending_errors(sync=True)
+
+    sm, _ = _random_model(dev, 4, **kw)                                                 # strict mode: raised by the call itself
+    sm.strict_indices = True
+    sm(good)
+    with pytest.raises(_lib.LcaoHipError, match="atomic number"):
+        sm(bad)
+
+    m, _ = _random_model(dev, 5, **kw)
+    with pytest.raises(_lib.LcaoHipError, match="atomic number"):
+        CapturedForward(m, bad)
+    step = CapturedForward(m, good)                                                     # and a valid capture still works
+    with torch.no_grad():
+        assert torch.equal(step(good["pos"]), m(good))
+    ops.raise_pending_errors(sync=True)
