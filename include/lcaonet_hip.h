@@ -264,6 +264,15 @@ int lcao_edge_node_message_agg_f16(const float* bw, const float* Ps, const float
                                    int64_t n_nodes, int64_t n_edges, int V, const int32_t* column_hint, float* msg,
                                    float* agg, void* stream);
 
+/* precision "f16": lcao_edge_lcao_weight_f16 + lcao_edge_node_message_agg_f16 as ONE call — with a column hint reading 1 or
+ * 2 one fused launch that never writes bw (E, V) (the three fp16 weight matrices share the LDS: 96 KB at V = 128); with a
+ * hint of 0, or none, the separate kernels through the bw / msg scratch rows ((n_edges, V) each, caller-owned, contents
+ * undefined afterwards).  V in {32, 64, 128}. */
+int lcao_edge_two_body_agg_f16(const float* tbw, const float* B, const float* W3, const float* Wb, const float* Ps,
+                               const float* Pt, const int32_t* src_p, const int32_t* dst_p, const int32_t* out_ptr,
+                               const float* Wn2, const float* bn2, int64_t n_nodes, int64_t n_edges, int V,
+                               const int32_t* column_hint, float* bw_scratch, float* msg_scratch, float* agg, void* stream);
+
 /* Species-pair form of lcaonet.py:170-183,200 (eval mode, no valence): with
  * Tf[(z_s*zdim + z_t), d, :] = f_coeffs(cst(z_s, z_t))[d, :] precomputed on the (zdim^2, D, V) pair table,
  *   A[p,l,:] = sum_{d in l} rb[e,d] * Tf[pair(p),d,:];  writes Ag = A * gate[src_p], B = sum_l A, gram = the triangular factor R (R^T R = A A^T, as above)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "lcao_node_column_hint": [P, L, L, P, P],
     "lcao_edge_node_message_agg_bf16x3": [P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],
     "lcao_edge_node_message_agg_f16": [P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],
+    "lcao_edge_two_body_agg_f16": [P, P, P, P, P, P, P, P, P, P, P, L, L, I, P, P, P, P, P],
     "lcao_edge_lcao_weight_saving": [P, P, P, P, L, I, P, P, P],
     "lcao_edge_node_message_saving": [P, P, P, P, P, P, P, L, I, P, P, P],
     "lcao_wgrad": [P, P, L, I, I, P, P, c_size_t, P],

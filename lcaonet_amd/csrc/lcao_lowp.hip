@@ -640,10 +640,12 @@ extern "C" int lcao_coeff_mlp_contract_f16(const void* cst16, const float* rb, c
 template <int PREC, int V>
 __global__ __launch_bounds__(256) void k_edge_lcao_weight_lowp(const float* __restrict__ tbw, const float* __restrict__ B,
                                                                const float* __restrict__ W3, const float* __restrict__ Wb,
-                                                               int64_t E, float* __restrict__ bw) {
+                                                               int64_t E, float* __restrict__ bw,
+                                                               const int32_t* __restrict__ skip_if /* nullable: return when it reads non-zero */) {
   typedef typename LowP<PREC>::T T;
   constexpr int MT = V / 16, KS = V / 32, NP = LowP<PREC>::PLANES;
   extern __shared__ unsigned char lds_raw[];
+  if (skip_if && *skip_if != 0) return;
   T* w3p = (T*)lds_raw;
   T* wbp = w3p + NP * V * V;
   stage_weights_lowp<PREC, false>(w3p, W3, V, V);
@@ -859,6 +861,177 @@ __global__ __launch_bounds__(256) void k_edge_node_message_cols_lowp(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// lcao_edge_two_body_agg_f16 — BOTH two-body kernels of a layer in one launch (lcaonet.py:192-213), fp16 only: W3, Wb and Wn2
+// as fp16 fragments are 96 KB of LDS (their fp32 or bf16-pair forms do not fit 160 KB together).  Node-column form as
+// k_edge_node_message_cols_lowp — step t takes the t-th out-edge of 16 consecutive centre nodes — with the basis weight
+// of that edge computed in place of loading it:
+//     ft = W3 . tbw ;  u = B (1 + ft) ;  lw = u / max(|u|, 1e-12) ;  bw = Wb . lw          (k_edge_lcao_weight_lowp)
+//     acc[s] += bw * SiLU(Wn2 . SiLU(Ps[s] + Pt[t]) + bn2)                                 (k_edge_node_message_cols_lowp)
+// bw (E, V) is neither written nor re-read (1 KB/edge/layer) and one launch per layer goes away.  96 MFMAs per step;
+// 512 threads = two waves per SIMD share the weights.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(512) void k_edge_two_body_cols_f16(
+    const float* __restrict__ tbw, const float* __restrict__ B, const float* __restrict__ Ps, const float* __restrict__ Pt,
+    const int32_t* __restrict__ dst_p, const int32_t* __restrict__ out_ptr, const float* __restrict__ W3,
+    const float* __restrict__ Wb, const float* __restrict__ Wn2, const float* __restrict__ bn2, int n_nodes, int n_edges,
+    const int32_t* __restrict__ hint, float* __restrict__ agg) {
+  constexpr int PREC = PREC_F16;
+  typedef _Float16 T;
+  constexpr int MT = V / 16, KS = V / 32, WAVES = 8;
+  extern __shared__ unsigned char lds_raw[];
+  if (hint && *hint == 0) return;
+  const bool by_degree = hint && *hint == 2;
+  T* w3p = (T*)lds_raw;
+  T* wbp = w3p + V * V;
+  T* wnp = wbp + V * V;
+  stage_weights_lowp<PREC, false>(w3p, W3, V, V);
+  stage_weights_lowp<PREC, true>(wbp, Wb, V, V);
+  stage_weights_lowp<PREC, false>(wnp, Wn2, V, V);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int n_groups = (n_nodes + 15) >> 4;
+  for (int g = blockIdx.x * WAVES + wave; g < n_groups; g += gridDim.x * WAVES) {
+    const bool node_ok = 16 * g + r < n_nodes;
+    const int slot = node_ok ? 16 * g + r : n_nodes - 1;
+    const int s = by_degree ? hint[1 + slot] : slot;          // nodes grouped by degree (lcao_node_column_hint, mode 2)
+    const int b = out_ptr[s];
+    const int deg = node_ok ? out_ptr[s + 1] - b : 0;
+    int Tn = deg;
+    Tn = max(Tn, __shfl_xor(Tn, 1)); Tn = max(Tn, __shfl_xor(Tn, 2)); Tn = max(Tn, __shfl_xor(Tn, 4)); Tn = max(Tn, __shfl_xor(Tn, 8));
+    Tn = __builtin_amdgcn_readfirstlane(Tn);
+    f32x4v acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    if (Tn > 0) {
+      auto edge_at = [&](int t) { return deg > 0 ? b + min(t, deg - 1) : min(b, n_edges - 1); };
+      const float* pr = Ps + (int64_t)s * V + 8 * q;   // the centre's own row: re-read per step (an L1 hit)
+      float hin[KS][8];
+      {
+        const float* pt = Pt + (int64_t)dst_p[edge_at(0)] * V + 8 * q;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const f32x4v a0 = *(const f32x4v*)(pt + 32 * k) + *(const f32x4v*)(pr + 32 * k);
+          const f32x4v a1 = *(const f32x4v*)(pt + 32 * k + 4) + *(const f32x4v*)(pr + 32 * k + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { hin[k][j] = lcao_silu(a0[j]); hin[k][4 + j] = lcao_silu(a1[j]); }
+        }
+      }
+      int d_nxt = dst_p[edge_at(1)];
+      f32x4v xt[KS][2], bn[MT];     // the three-body and B rows of a step are requested one step ahead (they stream from HBM)
+      {
+        const int64_t p0w = edge_at(0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          xt[k][0] = *(const f32x4v*)(tbw + p0w * V + 32 * k + 8 * q);
+          xt[k][1] = *(const f32x4v*)(tbw + p0w * V + 32 * k + 8 * q + 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bn[m] = *(const f32x4v*)(B + p0w * V + 16 * m + 4 * q);
+      }
+      for (int t = 0; t < Tn; ++t) {
+        asm volatile("" ::: "memory");
+        const float live = t < deg ? 1.0f : 0.0f;
+        // the NEXT step's rows: requested before the first GEMM
+        f32x4v bb[MT], ntv[KS][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bb[m] = bn[m];
+        LowpOperand<PREC> xop[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const float v[8] = {xt[k][0][0], xt[k][0][1], xt[k][0][2], xt[k][0][3], xt[k][1][0], xt[k][1][1], xt[k][1][2], xt[k][1][3]};
+          xop[k].set(v);
+        }
+        {
+          const int64_t pn = edge_at(t + 1);
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            xt[k][0] = *(const f32x4v*)(tbw + pn * V + 32 * k + 8 * q);
+            xt[k][1] = *(const f32x4v*)(tbw + pn * V + 32 * k + 8 * q + 4);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bn[m] = *(const f32x4v*)(B + edge_at(t + 1) * (int64_t)V + 16 * m + 4 * q);
+        {
+          const float* pt = Pt + (int64_t)d_nxt * V + 8 * q;
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            ntv[k][0] = *(const f32x4v*)(pt + 32 * k) + *(const f32x4v*)(pr + 32 * k);
+            ntv[k][1] = *(const f32x4v*)(pt + 32 * k + 4) + *(const f32x4v*)(pr + 32 * k + 4);
+          }
+        }
+        d_nxt = dst_p[edge_at(t + 2)];
+        // ---- message factor: SiLU(Wn2 . h1 + bn2), zero for a padded step
+        f32x4v o[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) o[m] = *(const f32x4v*)(bn2 + 16 * m + 4 * q);
+        {
+          LowpOperand<PREC> hop[KS];
+#pragma unroll
+          for (int k = 0; k < KS; ++k) hop[k].set(hin[k]);
+          lowp_layer<PREC, KS, MT>(wnp, V, V, r, q, hop, o);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[m][j] = live * lcao_silu(o[m][j]);
+        // ---- basis weight of this edge: f_three, injection, F.normalize, basis_weight
+        f32x4v ft[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ft[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        lowp_layer<PREC, KS, MT>(w3p, V, V, r, q, xop, ft);
+        float n2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float u = bb[m][j] + bb[m][j] * ft[m][j];
+            ft[m][j] = u;
+            n2 += u * u;
+          }
+        n2 += __shfl_xor(n2, 16);
+        n2 += __shfl_xor(n2, 32);
+        const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        f32x4v wv[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wv[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        {
+          LowpOperand<PREC> lop[KS];
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = ft[2 * k][j] * inv;
+              v[4 + j] = ft[2 * k + 1][j] * inv;
+            }
+            lop[k].set(v);
+          }
+          lowp_layer<PREC, KS, MT>(wbp, V, V, r, q, lop, wv);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] += wv[m] * o[m];
+        // first layer of the next step from the row requested above
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            hin[k][j] = lcao_silu(ntv[k][0][j]);
+            hin[k][4 + j] = lcao_silu(ntv[k][1][j]);
+          }
+      }
+    }
+    if (node_ok) {
+      float* out = agg + (int64_t)s * V + 4 * q;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) *(f32x4v*)(out + 16 * m) = acc[m];
+    }
+  }
+}
+
 // out[s, :] = sum of rows[out_ptr[s] : out_ptr[s+1], :]  (one wave per centre node, lanes over channels, fixed order);
 // returns at once when *skip_if reads 1
 __global__ void k_rows_segment_sum(const float* __restrict__ rows, const int32_t* __restrict__ out_ptr, int n_nodes, int V,
@@ -878,7 +1051,7 @@ __global__ void k_rows_segment_sum(const float* __restrict__ rows, const int32_t
 
 template <int PREC>
 static int edge_lcao_weight_lowp(const float* tbw, const float* B, const float* W3, const float* Wb, int64_t n_edges, int V,
-                                 float* bw, void* stream) {
+                                 float* bw, void* stream, const int32_t* skip_if = nullptr) {
   LCAO_CHECK_SIZE(n_edges);
   if (V <= 0) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
@@ -891,7 +1064,7 @@ static int edge_lcao_weight_lowp(const float* tbw, const float* B, const float* 
     int rc = set_lds_attr(k_edge_lcao_weight_lowp<PREC, V_>, lds, done);                                            \
     if (rc != LCAO_OK) return rc;                                                                                   \
     hipLaunchKernelGGL((k_edge_lcao_weight_lowp<PREC, V_>), dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, tbw, \
-                       B, W3, Wb, n_edges, bw);                                                                     \
+                       B, W3, Wb, n_edges, bw, skip_if);                                                            \
     return lcao_launch_status();                                                                                    \
   }
   LWL_CASE(128) LWL_CASE(64) LWL_CASE(32)
@@ -996,4 +1169,48 @@ extern "C" int lcao_edge_node_message_agg_f16(const float* bw, const float* Ps, 
                                               const int32_t* column_hint, float* msg, float* agg, void* stream) {
   return edge_node_message_agg_lowp<PREC_F16>(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, n_nodes, n_edges, V, column_hint,
                                               msg, agg, stream);
+}
+
+// The two-body half of a layer for precision "f16" (lcaonet.py:192-213): with a column hint reading 1 or 2 ONE fused launch
+// (k_edge_two_body_cols_f16); with 0 (uneven degrees) or without a hint the three separate kernels, through the bw / msg
+// scratch rows.  Every launch decides on the device from the hint word (no host sync).
+extern "C" int lcao_edge_two_body_agg_f16(const float* tbw, const float* B, const float* W3, const float* Wb, const float* Ps,
+                                          const float* Pt, const int32_t* src_p, const int32_t* dst_p, const int32_t* out_ptr,
+                                          const float* Wn2, const float* bn2, int64_t n_nodes, int64_t n_edges, int V,
+                                          const int32_t* column_hint, float* bw_scratch, float* msg_scratch, float* agg,
+                                          void* stream) {
+  LCAO_CHECK_SIZE(n_nodes);
+  LCAO_CHECK_SIZE(n_edges);
+  if (V <= 0 || V % 4) return LCAO_ERR_INVALID;
+  if (n_nodes == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(agg); LCAO_CHECK_PTR(out_ptr);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_edges == 0) return lcao_zero_async(agg, sizeof(float) * (size_t)n_nodes * V, st);
+  LCAO_CHECK_PTR(tbw); LCAO_CHECK_PTR(B); LCAO_CHECK_PTR(W3); LCAO_CHECK_PTR(Wb); LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt);
+  LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(Wn2); LCAO_CHECK_PTR(bn2); LCAO_CHECK_PTR(bw_scratch);
+  LCAO_CHECK_PTR(msg_scratch);
+  if (V != 128 && V != 64 && V != 32) return LCAO_ERR_UNSUPPORTED;
+  // uneven degrees (hint word 0) or no hint: basis weights, message rows, per-node sums; each returns at once otherwise
+  int rc = edge_lcao_weight_lowp<PREC_F16>(tbw, B, W3, Wb, n_edges, V, bw_scratch, stream, column_hint);
+  if (rc != LCAO_OK) return rc;
+  rc = edge_node_message_lowp<PREC_F16>(bw_scratch, Ps, Pt, src_p, dst_p, Wn2, bn2, n_edges, V, msg_scratch, stream, column_hint);
+  if (rc != LCAO_OK) return rc;
+  hipLaunchKernelGGL(k_rows_segment_sum, dim3(lcao_blocks(n_nodes, 4, 65536)), dim3(256), 0, st, msg_scratch, out_ptr,
+                     (int)n_nodes, V, column_hint, agg);
+  if (!column_hint) return lcao_launch_status();
+  const size_t lds = size_t(3) * V * V * 2;
+  int64_t cgroups = (((n_nodes + 15) >> 4) + 7) / 8, cap = (int64_t)lcao_num_cu() * (lds > 80 * 1024 ? 1 : 2);
+  if (cgroups > cap) cgroups = cap;
+#define TB_CASE(V_)                                                                                                   \
+  if (V == V_) {                                                                                                      \
+    static bool done = false;                                                                                         \
+    rc = set_lds_attr(k_edge_two_body_cols_f16<V_>, lds, done);                                                       \
+    if (rc != LCAO_OK) return rc;                                                                                     \
+    hipLaunchKernelGGL((k_edge_two_body_cols_f16<V_>), dim3((unsigned)cgroups), dim3(512), lds, st, tbw, B, Ps, Pt, dst_p, \
+                       out_ptr, W3, Wb, Wn2, bn2, (int)n_nodes, (int)n_edges, column_hint, agg);                      \
+    return lcao_launch_status();                                                                                      \
+  }
+  TB_CASE(128) TB_CASE(64) TB_CASE(32)
+#undef TB_CASE
+  return LCAO_ERR_UNSUPPORTED;
 }

@@ -393,11 +393,11 @@ class LCAOInteraction(nn.Module):
         Bv = Bv[:e_own] if Bv is not None else None
         # two-body term and messages
         if fused and not self.add_valence:
-            bw = ops.edge_lcao_weight(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach(), precision)
-            # message rows summed per centre inside the kernel (msg (E, V) exists only as the scratch of the 16-bit forms'
-            # fallback for uneven degrees)
-            agg = ops.edge_node_message_agg(bw, Ps, Pt, src_own, dst_own, out_ptr, self.f_node[2].weight.detach(),
-                                            self.f_node[2].bias.detach(), ctx.column_hint(out_ptr, e_own), precision)
+            # basis weights, then the message rows summed per centre inside the kernel (msg (E, V) exists only as the scratch
+            # of the 16-bit forms' fallback for uneven degrees); precision "f16": both in one launch, bw never written
+            agg = ops.edge_two_body_agg(tbw, B, self.f_three[0].weight.detach(), self.basis_weight.weight.detach(), Ps, Pt,
+                                        src_own, dst_own, out_ptr, self.f_node[2].weight.detach(),
+                                        self.f_node[2].bias.detach(), ctx.column_hint(out_ptr, e_own), precision)
         else:
             ft = run_mlp(self.f_three, tbw)
             lw = ops.edge_combine(ft, B, Bv)

@@ -617,6 +617,25 @@ def edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hi
     return agg
 
 
+def edge_two_body_agg(tbw, B, W3, Wb, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hint=None, precision="fp32"):
+    """agg (n_centres, V) of lcaonet.py:192-213: edge_lcao_weight followed by edge_node_message_agg.  precision "f16": one
+    C-ABI call (lcao_edge_two_body_agg_f16) — with a node-column hint one fused launch that never materialises bw."""
+    if precision != "f16":
+        bw = edge_lcao_weight(tbw, B, W3, Wb, precision)
+        return edge_node_message_agg(bw, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, column_hint, precision)
+    tbw, B, W3, Wb, Ps, Pt, Wn2, bn2 = (_f32(t) for t in (tbw, B, W3, Wb, Ps, Pt, Wn2, bn2))
+    E, V = B.shape
+    n = out_ptr.numel() - 1
+    dev = B.device
+    agg = torch.empty(n, V, device=dev, dtype=torch.float32)
+    bw = torch.empty(E, V, device=dev, dtype=torch.float32)      # scratch of the uneven-degree fallback only
+    msg = torch.empty(E, V, device=dev, dtype=torch.float32)
+    _call("lcao_edge_two_body_agg_f16", _p(tbw), _p(B), _p(W3), _p(Wb), _p(Ps), _p(Pt), _p(_i32(src_p)), _p(_i32(dst_p)),
+          _p(_i32(out_ptr)), _p(Wn2), _p(bn2), n, E, V, _p(column_hint) if column_hint is not None else None, _p(bw), _p(msg),
+          _p(agg), _stream())
+    return agg
+
+
 # --- activation-gradient kernels (autograd forces at inference; csrc/lcao_backward.hip) -------------------------
 def message_bwd_fused(g_agg, src_p, dst_p, bw, pre2, Ps, Pt, Wn2T, want_g_pre2=False):
     """(g_bw, g_pre1, g_pre2|None): message product, second f_node layer and SiLU'(pre1) differentiated in one kernel."""
