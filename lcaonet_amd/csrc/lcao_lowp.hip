@@ -637,8 +637,10 @@ extern "C" int lcao_coeff_mlp_contract_f16(const void* cst16, const float* rb, c
 // ===================================================================================================
 // low-precision forms of the two-body kernels (same operand treatment; `precision="bf16x3"` / `"f16"`)
 // ===================================================================================================
-template <int PREC, int V>
-__global__ __launch_bounds__(256) void k_edge_lcao_weight_lowp(const float* __restrict__ tbw, const float* __restrict__ B,
+// THREADS = 512 where the weight planes leave room for one workgroup per CU only (bf16x3 at V = 128: 128 KB): two waves per
+// SIMD then share them; 256 otherwise (two workgroups per CU).
+template <int PREC, int V, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_edge_lcao_weight_lowp(const float* __restrict__ tbw, const float* __restrict__ B,
                                                                const float* __restrict__ W3, const float* __restrict__ Wb,
                                                                int64_t E, float* __restrict__ bw,
                                                                const int32_t* __restrict__ skip_if /* nullable: return when it reads non-zero */) {
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void k_edge_lcao_weight_lowp(const float* __re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t n_tiles = (E + 15) >> 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+  for (int64_t tile = (int64_t)blockIdx.x * (THREADS / 64) + wave; tile < n_tiles; tile += (int64_t)gridDim.x * (THREADS / 64)) {
     asm volatile("" ::: "memory");
     const int64_t p = tile * 16 + r;
     const bool valid = p < E;
@@ -1060,11 +1062,12 @@ static int edge_lcao_weight_lowp(const float* tbw, const float* B, const float* 
   size_t lds = size_t(2) * LowP<PREC>::PLANES * V * V * 2;
 #define LWL_CASE(V_)                                                                                                \
   if (V == V_) {                                                                                                    \
+    constexpr int TH = (size_t(2) * LowP<PREC>::PLANES * V_ * V_ * 2 > 80 * 1024) ? 512 : 256;                      \
     static bool done = false;                                                                                       \
-    int rc = set_lds_attr(k_edge_lcao_weight_lowp<PREC, V_>, lds, done);                                            \
+    int rc = set_lds_attr(k_edge_lcao_weight_lowp<PREC, V_, TH>, lds, done);                                        \
     if (rc != LCAO_OK) return rc;                                                                                   \
-    hipLaunchKernelGGL((k_edge_lcao_weight_lowp<PREC, V_>), dim3(persistent_groups(n_edges, lds)), dim3(256), lds, st, tbw, \
-                       B, W3, Wb, n_edges, bw, skip_if);                                                            \
+    hipLaunchKernelGGL((k_edge_lcao_weight_lowp<PREC, V_, TH>), dim3(persistent_groups(n_edges, lds, TH / 64)), dim3(TH), lds, \
+                       st, tbw, B, W3, Wb, n_edges, bw, skip_if);                                                   \
     return lcao_launch_status();                                                                                    \
   }
   LWL_CASE(128) LWL_CASE(64) LWL_CASE(32)
