@@ -1859,9 +1859,7 @@ __device__ __forceinline__ void tbwd_short_in_tile(
         f32x4v gw = f32x4v{0.f, 0.f, 0.f, 0.f};
         const int rem = m_out - it;
         if (rem <= 4) {
-#pragma unroll
-          for (int pp = 0; pp < 4; ++pp) {
-            if (pp >= rem) break;
+          for (int pp = 0; pp < rem; ++pp) {   // wave-uniform trip count <= 4
             const float* gtp = g_tbw + (int64_t)(p0 + it + pp) * V + 4 * quarter;
             f32x4v t4 = *(const f32x4v*)(gtp) * xb[0];
 #pragma unroll
@@ -2059,9 +2057,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
               // rows at full price (96 MFMAs).  The <= 4 x 16 x NL dot products run on the VALU instead: this lane's 32
               // channels of its in-edge against the same channels of each out-edge row (a broadcast load per 16 lanes),
               // then the four quarters are summed.  rem x 32 NL FMAs per lane, ~1/4 of the MFMA time at rem = 2.
-#pragma unroll
-              for (int pp = 0; pp < 4; ++pp) {
-                if (pp >= rem) break;   // wave-uniform
+              for (int pp = 0; pp < rem; ++pp) {   // wave-uniform trip count <= 4
                 const float* gtp = g_tbw + (int64_t)(p0 + it + pp) * V + 4 * quarter;
                 f32x4v ga[KT];
 #pragma unroll
