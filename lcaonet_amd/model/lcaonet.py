@@ -362,7 +362,7 @@ class LCAOInteraction(nn.Module):
                 Ag, gram, B = pc(Tf)
                 Bv = None
             tbw = ops.triplet_gemm(Ag, gram, ctx.uvec_p(uvec), in_ptr, ctx.in_pos, out_ptr, e_own)
-        elif fused and precision in ops.LOWP and not self.add_valence and cst.shape[-1] == V:
+        elif fused and precision in ops.LOWP and not self.add_valence and cst.shape[-1] == V and rb.shape[1] <= ops.LOWP_MAX_ORBITALS:
             # BASELINE config 3: 16-bit MFMA on the per-edge coefficient GEMMs (bf16 split in two terms, or plain fp16)
             Ag, gram, B, Bv = ops.coeff_mlp_contract_bf16x3(
                 cst, rb, ctx.order, l_of_d, self.f_coeffs[0].weight.detach(), self.f_coeffs[2].weight.detach(), n_l,
@@ -765,7 +765,7 @@ class LCAONet(BaseMPNN):
         # 16-bit coefficient kernels: the MFMA operands of cst, prepared once (cst is the same in every interaction)
         cst16 = None
         if (precision in ops.LOWP and pair is None and fused is not False and not self.add_valence
-                and self.emb_size_coeff == self.emb_size_conv
+                and self.emb_size_coeff == self.emb_size_conv and self.elec_info.n_orb <= ops.LOWP_MAX_ORBITALS
                 and all(layer._fusable(self.emb_size_coeff) for layer in self.int_layers)):
             cst16 = ops.lowp_pack_rows(cst, precision)
 

@@ -340,6 +340,8 @@ def coeff_contract(cstf, rb, order, l_of_d, mask, V, n_l, valence):
 
 
 LOWP = ("bf16x3", "f16")    # precision modes of the 16-bit matrix path (csrc/lcao_lowp.hip)
+LOWP_MAX_ORBITALS = 32      # the 16-bit coefficient kernel keeps the orbitals of each l in a 32-bit mask; more orbitals
+                            # (e.g. max_z = 96 with n_per_orb = 2) run the fp32 coefficient kernel, the rest of the layer in 16 bits
 
 
 _PREC_CODE = {"bf16x3": 0, "f16": 1}    # LCAO_PREC_* of include/lcaonet_hip.h

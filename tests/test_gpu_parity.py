@@ -1359,3 +1359,18 @@ def test_index_checks_cover_forces_training_and_captures(dev):
     with torch.no_grad():
         assert torch.equal(step(good["pos"]), m(good))
     ops.raise_pending_errors(sync=True)
+
+
+@pytest.mark.gpu
+def test_lowp_precision_with_more_than_32_orbitals(dev):
+    """The 16-bit coefficient kernel keeps the orbitals of each l in a 32-bit mask; max_z = 96 with n_per_orb = 2 has 36
+    orbitals: the model then runs the fp32 coefficient kernel and the rest of the layer in 16 bits instead of raising."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=32, n_interaction=2, cutoff=5.0, max_z=96, n_per_orb=2)
+    m, sd = _random_model(dev, 77, **kw)
+    assert m.elec_info.n_orb == 36
+    g = random_periodic_cells(2, 10, 6.2, 0.99 * 5.0, seed=9, max_z=96)
+    want, _ = _oracle_run(sd, kw, g.to_dict())
+    for precision in ("f16", "bf16x3"):
+        got = m(g.to(dev), precision=precision)
+        assert relerr(got, want) <= 3e-3
