@@ -910,20 +910,30 @@ __global__ __launch_bounds__(512) void k_edge_two_body_cols_f16(
     for (int m = 0; m < MT; ++m) acc[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
     if (Tn > 0) {
       auto edge_at = [&](int t) { return deg > 0 ? b + min(t, deg - 1) : min(b, n_edges - 1); };
-      const float* pr = Ps + (int64_t)s * V + 8 * q;   // the centre's own row: re-read per step (an L1 hit)
+      // the centre's own row stays in registers for the group; the target row of a step is requested one step ahead and
+      // only ADDED to it when the step is over (an add right at the load would make the wave wait for the gather at once)
+      f32x4v psr[KS][2];
+      {
+        const float* pr = Ps + (int64_t)s * V + 8 * q;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          psr[k][0] = *(const f32x4v*)(pr + 32 * k);
+          psr[k][1] = *(const f32x4v*)(pr + 32 * k + 4);
+        }
+      }
       float hin[KS][8];
       {
         const float* pt = Pt + (int64_t)dst_p[edge_at(0)] * V + 8 * q;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-          const f32x4v a0 = *(const f32x4v*)(pt + 32 * k) + *(const f32x4v*)(pr + 32 * k);
-          const f32x4v a1 = *(const f32x4v*)(pt + 32 * k + 4) + *(const f32x4v*)(pr + 32 * k + 4);
+          const f32x4v a0 = *(const f32x4v*)(pt + 32 * k) + psr[k][0];
+          const f32x4v a1 = *(const f32x4v*)(pt + 32 * k + 4) + psr[k][1];
 #pragma unroll
           for (int j = 0; j < 4; ++j) { hin[k][j] = lcao_silu(a0[j]); hin[k][4 + j] = lcao_silu(a1[j]); }
         }
       }
       int d_nxt = dst_p[edge_at(1)];
-      f32x4v xt[KS][2], bn[MT];     // the three-body and B rows of a step are requested one step ahead (they stream from HBM)
+      f32x4v xt[KS][2];     // the three-body row of a step is requested one step ahead (it streams from HBM)
       {
         const int64_t p0w = edge_at(0);
 #pragma unroll
@@ -931,16 +941,14 @@ __global__ __launch_bounds__(512) void k_edge_two_body_cols_f16(
           xt[k][0] = *(const f32x4v*)(tbw + p0w * V + 32 * k + 8 * q);
           xt[k][1] = *(const f32x4v*)(tbw + p0w * V + 32 * k + 8 * q + 4);
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) bn[m] = *(const f32x4v*)(B + p0w * V + 16 * m + 4 * q);
       }
       for (int t = 0; t < Tn; ++t) {
         asm volatile("" ::: "memory");
         const float live = t < deg ? 1.0f : 0.0f;
-        // the NEXT step's rows: requested before the first GEMM
+        // this step's B row (needed after two GEMMs) and the NEXT step's rows: requested before the first GEMM
         f32x4v bb[MT], ntv[KS][2];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) bb[m] = bn[m];
+        for (int m = 0; m < MT; ++m) bb[m] = *(const f32x4v*)(B + edge_at(t) * (int64_t)V + 16 * m + 4 * q);
         LowpOperand<PREC> xop[KS];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
@@ -955,14 +963,12 @@ __global__ __launch_bounds__(512) void k_edge_two_body_cols_f16(
             xt[k][1] = *(const f32x4v*)(tbw + pn * V + 32 * k + 8 * q + 4);
           }
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) bn[m] = *(const f32x4v*)(B + edge_at(t + 1) * (int64_t)V + 16 * m + 4 * q);
         {
           const float* pt = Pt + (int64_t)d_nxt * V + 8 * q;
 #pragma unroll
           for (int k = 0; k < KS; ++k) {
-            ntv[k][0] = *(const f32x4v*)(pt + 32 * k) + *(const f32x4v*)(pr + 32 * k);
-            ntv[k][1] = *(const f32x4v*)(pt + 32 * k + 4) + *(const f32x4v*)(pr + 32 * k + 4);
+            ntv[k][0] = *(const f32x4v*)(pt + 32 * k);
+            ntv[k][1] = *(const f32x4v*)(pt + 32 * k + 4);
           }
         }
         d_nxt = dst_p[edge_at(t + 2)];
@@ -1021,8 +1027,8 @@ __global__ __launch_bounds__(512) void k_edge_two_body_cols_f16(
         for (int k = 0; k < KS; ++k)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            hin[k][j] = lcao_silu(ntv[k][0][j]);
-            hin[k][4 + j] = lcao_silu(ntv[k][1][j]);
+            hin[k][j] = lcao_silu(ntv[k][0][j] + psr[k][0][j]);
+            hin[k][4 + j] = lcao_silu(ntv[k][1][j] + psr[k][1][j]);
           }
       }
     }
