@@ -440,6 +440,33 @@ int lcao_rownorm_levels(int level, const float* x, const float* g, const float* 
 int lcao_mulp_levels(int level, const float* a, const float* b, const float* g, const float* ha, const float* hb, float c0,
                      int64_t n, float* out0, float* out1, float* out2, void* stream);
 
+/* The orbital contraction in species-pair form TOGETHER with its consumers (lcaonet.py:170-186, 200-203), as one map with
+ * derivative levels — A (E, n_l, V) itself is never stored, every level rebuilds it from rb (E, D) and the table rows
+ * Tf (zdim^2, D, V).  p-space rows; gate (N, V) is read at src_p; gG / o_gram are full (E, n_l, n_l) matrices.
+ *   level 0: o_big0 = Ag = A gate[src] (E, n_l, V), o_row0 = B = sum_l A (E, V), o_gram = G = A A^T
+ *   level 1 (cotangents gAg, gB, gG of level 0): o_rb = dE/drb (E, D), o_row1 = sum_l gAg[l] A[l] (E, V; its segment sum
+ *            over the out-edges of a node is dE/dgate), optional o_gA = dE/dA (E, n_l, V) for lcao_pair_table_grad
+ *   level 2 (cotangents h_rb (E, D), h_gate (N, V) or NULL of level 1's o_rb and of the segment-summed o_row1):
+ *            o_big0 = d/dgAg, o_row0 = d/dgB, o_gram = d/dgG, o_rb = d/drb, o_row1 = the per-edge part of d/dgate,
+ *            optional o_gA = dE/dA of level 1 and o_dA = d/dA (both or neither): d/dTf = table_grad(o_gA, h_rb) +
+ *            table_grad(o_dA, rb).
+ * V in {32, 64, 128} (UNSUPPORTED otherwise), n_l <= 4.  (model/double.py::_ASideFn) */
+int lcao_aside_levels(int level, const float* Tf, const float* rb, const int32_t* l_of_d, const int64_t* z,
+                      const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* gAg, const float* gB,
+                      const float* gG, const float* h_rb, const float* h_gate, int64_t n_edges, int n_orb, int V, int n_l,
+                      int zdim, float* o_big0, float* o_row0, float* o_gram, float* o_rb, float* o_row1, float* o_gA,
+                      float* o_dA, void* stream);
+
+/* Two fused maps of the edge chain with the same derivative levels (the tensor between the two fused steps is never
+ * stored): injnorm y = x / max(|x|, eps) per row with x = a (1 + b)  (lcaonet.py:192-196: a = B, b = ft) and
+ * silumul m = a silu(x)  (lcaonet.py:209-211: a = bw, x = f_node's last pre-activation).  Level 0: out0 = f; level 1
+ * (cotangent g): out0 = d/da, out1 = d/d(b or x); level 2 (cotangents ha, hb / hx of level 1's outputs): out0 = d/dg,
+ * out1 = d/da, out2 = d/d(b or x).  silumul: n % 4 == 0 and 16-byte aligned operands. */
+int lcao_injnorm_levels(int level, const float* a, const float* b, const float* g, const float* ha, const float* hb,
+                        int64_t n_rows, int V, float eps, float* out0, float* out1, float* out2, void* stream);
+int lcao_silumul_levels(int level, const float* a, const float* x, const float* g, const float* ha, const float* hx,
+                        int64_t n, float* out0, float* out1, float* out2, void* stream);
+
 /* The gated copy Ag = A * gate[src] (lcaonet.py:186, broadcast over l) and B = sum_l A (:200-203) with the terms of their two
  * derivative levels:  bcast_fma: out[e,l,:] = X1[e,l,:] y1[e,:] (+ X2[e,l,:] y2[e,:]) (+ z[e,:]);
  *                     lsum_mul : out[e,:] = sum_l X[e,l,:] (Y[e,l,:] or 1).   X (E, L, V), y / z / out (E, V); V % 4 == 0. */

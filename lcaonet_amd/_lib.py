@@ -85,6 +85,9 @@ SIGNATURES = {
     "lcao_trip_weight_bwd2": [P, P, P, P, P, P, P, P, P, P, L, L, I, P, P, P, P],
     "lcao_radial_levels": [I, P, P, P, L, I, P, I, I, F, P, P, P],
     "lcao_mulp_levels": [I, P, P, P, P, P, F, L, P, P, P, P],
+    "lcao_aside_levels": [I, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, P, P, P, P, P, P, P],
+    "lcao_injnorm_levels": [I, P, P, P, P, P, L, I, F, P, P, P, P],
+    "lcao_silumul_levels": [I, P, P, P, P, P, L, P, P, P, P],
     "lcao_bcast_fma": [P, P, P, P, P, L, I, I, P, P],
     "lcao_lsum_mul": [P, P, L, I, I, P, P],
     "lcao_silu_levels": [I, P, P, P, L, P, P, P],

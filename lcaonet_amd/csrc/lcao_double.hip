@@ -1118,3 +1118,349 @@ extern "C" int lcao_lsum_mul(const float* X, const float* Y, int64_t n_edges, in
                      n_edges, L, V / 4, out);
   return lcao_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The orbital contraction with everything that consumes it, as ONE map with closed-form derivative levels
+// (lcaonet.py:170-186, 200-203 in species-pair form; model/double.py::_ASideFn):
+//     A[p,l,:] = sum_{d in l} rb[p,d] T[pair(p),d,:]      Ag = A gate[src(p)]      B = sum_l A      G = A A^T  (n_l x n_l)
+//   level 0: (rb, T, gate)                          -> Ag, B, G
+//   level 1: + cotangents (gAg, gB, gG)             -> g_rb[p,d] = gA[l(d)] . T[d],  g_gate_part[p,:] = sum_l gAg[l] A[l],
+//                                                      with gA[l] = gAg[l] gate + gB + sum_m (gG[l,m] + gG[m,l]) A[m]
+//   level 2: + cotangents (h_rb, h_gate) of level 1 -> the derivative of  L2 = sum_d h_rb[d] g_rb[d] + h_gate[src] . g_gate_part
+//            with respect to gAg, gB, gG, rb, gate[src] — and gA, dA = dL2/dA for the two table gradients
+//            dL2/dT = table_grad(gA, h_rb) + table_grad(dA, rb).  With Ah[l] = sum_{d in l} h_rb[d] T[d]:
+//                d gAg[l] = gate Ah[l] + h_gate A[l]        d gB = sum_l Ah[l]        d gG[l,m] = Ah[l].A[m] + Ah[m].A[l]
+//                d gate_part = sum_l gAg[l] Ah[l]           dA[m] = sum_l S[l,m] Ah[l] + h_gate gAg[m]     d rb[d] = dA[l(d)] . T[d]
+// A (E, n_l, V) is never stored: each level rebuilds it from rb and the table rows (L2-resident: zdim^2 x D x V floats).
+// The level-1 map does not return dE/dT (the force pass wants positions only), so level 2 has no h_T.
+// 16 lanes per edge (4 edges per wave), float4 channel chunks, DPP row reductions; V in {32, 64, 128}.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int V, int NL, int LEVEL>
+__global__ __launch_bounds__(256) void k_aside(
+    const float* __restrict__ Tf, const float* __restrict__ rb, const int32_t* __restrict__ l_of_d,
+    const int64_t* __restrict__ z, const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p,
+    const float* __restrict__ gate, const float* __restrict__ gAg, const float* __restrict__ gB,
+    const float* __restrict__ gG, const float* __restrict__ h_rb, const float* __restrict__ h_gate, int64_t E, int D,
+    int zdim, float* __restrict__ o_big0, float* __restrict__ o_row0, float* __restrict__ o_gram,
+    float* __restrict__ o_rb, float* __restrict__ o_row1, float* __restrict__ o_gA, float* __restrict__ o_dA) {
+  constexpr int NC = (V + 63) / 64;
+  const int sub = threadIdx.x & 15, rowi = (threadIdx.x & 63) >> 4;
+  const bool chv0 = 4 * sub < V;                                   // V = 32: the upper half of the 16 lanes idles
+  int64_t p0 = ((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6) * 4;
+  const int64_t stride = (((int64_t)gridDim.x * blockDim.x) >> 6) * 4;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (; p0 < E; p0 += stride) {
+    const int64_t p = p0 + rowi;
+    const bool valid = p < E;
+    const int64_t pc = valid ? p : E - 1;
+    const int s = src_p[pc];
+    const int64_t pair = z[s] * zdim + z[dst_p[pc]];
+    const float* t = Tf + pair * (int64_t)D * V + 4 * sub;
+    f32x4 a[NL][NC], ah[NL][NC];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { a[l][c] = zero4; ah[l][c] = zero4; }
+    for (int d = 0; d < D; ++d) {
+      const float w = rb[pc * D + d];
+      const float wh = LEVEL == 2 ? h_rb[pc * D + d] : 0.f;
+      const int l = l_of_d[d];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const f32x4 tv = chv0 ? *(const f32x4*)(t + d * V + 64 * c) : zero4;
+#pragma unroll
+        for (int ll = 0; ll < NL; ++ll) {
+          a[ll][c] += (l == ll ? w : 0.f) * tv;
+          if (LEVEL == 2) ah[ll][c] += (l == ll ? wh : 0.f) * tv;
+        }
+      }
+    }
+    float S[NL][NL];
+    if (LEVEL >= 1) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int m = 0; m < NL; ++m) S[l][m] = gG[(pc * NL + l) * NL + m] + gG[(pc * NL + m) * NL + l];
+    }
+    f32x4 cot[NL][NC];                      // level 1: gA, level 2: dA — contracted with the table rows afterwards
+    float dots[NL][NL];                     // level 0: A.A, level 2: Ah.A
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int m = 0; m < NL; ++m) dots[l][m] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int64_t off = 64 * c + 4 * sub;
+      const bool st = valid && chv0;
+      const f32x4 ge = chv0 ? *(const f32x4*)(gate + (int64_t)s * V + off) : zero4;
+      if (LEVEL == 0) {
+        f32x4 b = zero4;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          b += a[l][c];
+          if (st) *(f32x4*)(o_big0 + (p * NL + l) * V + off) = a[l][c] * ge;
+#pragma unroll
+          for (int m = l; m < NL; ++m) {
+            const f32x4 q = a[l][c] * a[m][c];
+            dots[l][m] += q[0] + q[1] + q[2] + q[3];
+          }
+        }
+        if (st) *(f32x4*)(o_row0 + p * V + off) = b;
+      } else {
+        const f32x4 gb = chv0 ? *(const f32x4*)(gB + pc * V + off) : zero4;
+        f32x4 gag[NL], gA[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) gag[l] = chv0 ? *(const f32x4*)(gAg + (pc * NL + l) * V + off) : zero4;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          f32x4 v = gag[l] * ge + gb;
+#pragma unroll
+          for (int m = 0; m < NL; ++m) v += S[l][m] * a[m][c];
+          gA[l] = v;
+        }
+        if (LEVEL == 1) {
+          f32x4 gpart = zero4;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            gpart += gag[l] * a[l][c];
+            cot[l][c] = gA[l];
+            if (o_gA && st) *(f32x4*)(o_gA + (p * NL + l) * V + off) = gA[l];
+          }
+          if (st) *(f32x4*)(o_row1 + p * V + off) = gpart;
+        } else {
+          const f32x4 hge = (h_gate && chv0) ? *(const f32x4*)(h_gate + (int64_t)s * V + off) : zero4;
+          f32x4 dgb = zero4, dgp = zero4;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            dgb += ah[l][c];
+            dgp += gag[l] * ah[l][c];
+            if (st) *(f32x4*)(o_big0 + (p * NL + l) * V + off) = ge * ah[l][c] + hge * a[l][c];
+            f32x4 da = hge * gag[l];
+#pragma unroll
+            for (int m = 0; m < NL; ++m) {
+              da += S[m][l] * ah[m][c];
+              const f32x4 q = ah[l][c] * a[m][c];
+              dots[l][m] += q[0] + q[1] + q[2] + q[3];
+            }
+            cot[l][c] = da;
+            if (o_gA && st) {
+              *(f32x4*)(o_gA + (p * NL + l) * V + off) = gA[l];
+              *(f32x4*)(o_dA + (p * NL + l) * V + off) = da;
+            }
+          }
+          if (st) {
+            *(f32x4*)(o_row0 + p * V + off) = dgb;
+            *(f32x4*)(o_row1 + p * V + off) = dgp;
+          }
+        }
+      }
+    }
+    if (LEVEL != 1) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int m = (LEVEL == 0 ? l : 0); m < NL; ++m) dots[l][m] = lcao_row16_sum(dots[l][m]);
+      if (valid && sub == 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int m = 0; m < NL; ++m)
+            o_gram[(p * NL + l) * NL + m] = LEVEL == 0 ? (l <= m ? dots[l][m] : dots[m][l]) : dots[l][m] + dots[m][l];
+      }
+    }
+    if (LEVEL >= 1) {
+      for (int d = 0; d < D; ++d) {
+        const int l = l_of_d[d];
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const f32x4 tv = chv0 ? *(const f32x4*)(t + d * V + 64 * c) : zero4;
+          f32x4 gsel = zero4;
+#pragma unroll
+          for (int ll = 0; ll < NL; ++ll) gsel = (l == ll) ? cot[ll][c] : gsel;
+          acc += gsel[0] * tv[0] + gsel[1] * tv[1] + gsel[2] * tv[2] + gsel[3] * tv[3];
+        }
+        acc = lcao_row16_sum(acc);
+        if (valid && sub == 0) o_rb[p * D + d] = acc;
+      }
+    }
+  }
+}
+
+extern "C" int lcao_aside_levels(int level, const float* Tf, const float* rb, const int32_t* l_of_d, const int64_t* z,
+                                 const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* gAg,
+                                 const float* gB, const float* gG, const float* h_rb, const float* h_gate, int64_t n_edges,
+                                 int n_orb, int V, int n_l, int zdim, float* o_big0, float* o_row0, float* o_gram,
+                                 float* o_rb, float* o_row1, float* o_gA, float* o_dA, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (level < 0 || level > 2 || n_orb <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0) return LCAO_ERR_INVALID;
+  if (V != 32 && V != 64 && V != 128) return LCAO_ERR_UNSUPPORTED;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(Tf); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p);
+  LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(gate);
+  if (level == 0) { LCAO_CHECK_PTR(o_big0); LCAO_CHECK_PTR(o_row0); LCAO_CHECK_PTR(o_gram); }
+  if (level >= 1) { LCAO_CHECK_PTR(gAg); LCAO_CHECK_PTR(gB); LCAO_CHECK_PTR(gG); LCAO_CHECK_PTR(o_rb); LCAO_CHECK_PTR(o_row1); }
+  if (level == 2) {
+    LCAO_CHECK_PTR(h_rb); LCAO_CHECK_PTR(o_big0); LCAO_CHECK_PTR(o_row0); LCAO_CHECK_PTR(o_gram);
+    if ((o_gA == nullptr) != (o_dA == nullptr)) return LCAO_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n_edges, 16, 65536)), block(256);
+#define AS_L(V_, NL_, LV_)                                                                                             \
+  hipLaunchKernelGGL((k_aside<V_, NL_, LV_>), grid, block, 0, st, Tf, rb, l_of_d, z, src_p, dst_p, gate, gAg, gB, gG, h_rb, \
+                     h_gate, n_edges, n_orb, zdim, o_big0, o_row0, o_gram, o_rb, o_row1, o_gA, o_dA)
+#define AS_NL(V_, NL_)                                                                                                 \
+  if (V == V_ && n_l == NL_) {                                                                                         \
+    if (level == 0) AS_L(V_, NL_, 0);                                                                                  \
+    else if (level == 1) AS_L(V_, NL_, 1);                                                                             \
+    else AS_L(V_, NL_, 2);                                                                                             \
+    return lcao_launch_status();                                                                                       \
+  }
+#define AS_V(V_) AS_NL(V_, 1) AS_NL(V_, 2) AS_NL(V_, 3) AS_NL(V_, 4)
+  AS_V(128) AS_V(64) AS_V(32)
+#undef AS_V
+#undef AS_NL
+#undef AS_L
+  return LCAO_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two more maps of the edge chain with their derivative levels, each the fusion of two of the above so that the tensor
+// between them is never stored:
+//   injnorm (lcaonet.py:192-196): y = x / max(|x|, eps) with x = a (1 + b)   (a = B, b = ft; mulp then rownorm)
+//     level 1 (cotangent g of y): gx = (g - y (y.g)) / n;  out0 = gx (1 + b) [d/da], out1 = gx a [d/db]
+//     level 2 (cotangents ha, hb of level 1's outputs): k = ha (1 + b) + hb a;  out0 = (k - y (y.k)) / n [d/dg];
+//             dx = ((3 (y.k)(y.g) - k.g) y - (y.g) k - (y.k) g) / n^2;  out1 = dx (1 + b) + hb gx [d/da],  out2 = dx a + ha gx [d/db]
+//   silumul (lcaonet.py:209-211): m = a silu(x)   (a = bw, x = the pre-activation of f_node's last layer; silu then mulp)
+//     level 1 (cotangent g): out0 = g s [d/da], out1 = g a s1 [d/dx]
+//     level 2 (cotangents ha, hx): out0 = ha s + hx a s1 [d/dg], out1 = hx g s1 [d/da], out2 = ha g s1 + hx g a s2 [d/dx]
+// ---------------------------------------------------------------------------------------------------------------------
+template <int R, int LEVEL>
+__global__ void k_injnorm_levels(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                                 const float* __restrict__ ha, const float* __restrict__ hb, int64_t n_rows, int V,
+                                 float eps, float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; e < n_rows; e += nwave) {
+    float av[R], bv[R], xv[R], gv[R], kv[R], hav[R], hbv[R];
+    float n2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ch = lane + 64 * r;
+      const bool ok = ch < V;
+      av[r] = ok ? a[e * V + ch] : 0.f;
+      bv[r] = ok ? 1.0f + b[e * V + ch] : 0.f;
+      gv[r] = (LEVEL >= 1 && ok) ? g[e * V + ch] : 0.f;
+      hav[r] = (LEVEL >= 2 && ok) ? ha[e * V + ch] : 0.f;
+      hbv[r] = (LEVEL >= 2 && ok) ? hb[e * V + ch] : 0.f;
+      xv[r] = av[r] * bv[r];
+      kv[r] = hav[r] * bv[r] + hbv[r] * av[r];
+      n2 += xv[r] * xv[r];
+    }
+    const float n = sqrtf(lcao_wave_sum(n2));
+    const bool live = n > eps;
+    const float inv = 1.0f / fmaxf(n, eps);
+    float ad = 0.f, bd = 0.f, d = 0.f;
+    if (LEVEL >= 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        bd += xv[r] * gv[r];
+        if (LEVEL >= 2) {
+          ad += xv[r] * kv[r];
+          d += kv[r] * gv[r];
+        }
+      }
+      bd = lcao_wave_sum(bd) * inv;
+      if (LEVEL >= 2) {
+        ad = lcao_wave_sum(ad) * inv;
+        d = lcao_wave_sum(d);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ch = lane + 64 * r;
+      if (ch >= V) continue;
+      const float y = xv[r] * inv;
+      if (LEVEL == 0) o0[e * V + ch] = y;
+      if (LEVEL >= 1) {
+        const float gx = live ? (gv[r] - y * bd) * inv : gv[r] * inv;
+        if (LEVEL == 1) {
+          o0[e * V + ch] = gx * bv[r];
+          o1[e * V + ch] = gx * av[r];
+        } else {
+          const float dx = live ? ((3.0f * ad * bd - d) * y - bd * kv[r] - ad * gv[r]) * (inv * inv) : 0.f;
+          o0[e * V + ch] = live ? (kv[r] - y * ad) * inv : kv[r] * inv;
+          o1[e * V + ch] = dx * bv[r] + hbv[r] * gx;
+          o2[e * V + ch] = dx * av[r] + hav[r] * gx;
+        }
+      }
+    }
+  }
+}
+
+template <int LEVEL>
+__global__ void k_silumul_levels(const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ g,
+                                 const float* __restrict__ ha, const float* __restrict__ hx, int64_t n,
+                                 float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4v av = *(const f32x4v*)(a + i), xv = *(const f32x4v*)(x + i);
+    const f32x4v gv = LEVEL >= 1 ? *(const f32x4v*)(g + i) : z4;
+    const f32x4v hav = LEVEL == 2 ? *(const f32x4v*)(ha + i) : z4, hxv = LEVEL == 2 ? *(const f32x4v*)(hx + i) : z4;
+    f32x4v r0, r1, r2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sg = 1.0f / (1.0f + __expf(-xv[j]));
+      const float s = xv[j] * sg;
+      const float s1 = sg * (1.0f + xv[j] * (1.0f - sg));
+      if (LEVEL == 0) r0[j] = av[j] * s;
+      if (LEVEL == 1) { r0[j] = gv[j] * s; r1[j] = gv[j] * av[j] * s1; }
+      if (LEVEL == 2) {
+        const float s2 = sg * (1.0f - sg) * (2.0f + xv[j] * (1.0f - 2.0f * sg));
+        r0[j] = hav[j] * s + hxv[j] * av[j] * s1;
+        r1[j] = hxv[j] * gv[j] * s1;
+        r2[j] = gv[j] * (hav[j] * s1 + hxv[j] * av[j] * s2);
+      }
+    }
+    *(f32x4v*)(o0 + i) = r0;
+    if (LEVEL >= 1) *(f32x4v*)(o1 + i) = r1;
+    if (LEVEL == 2) *(f32x4v*)(o2 + i) = r2;
+  }
+}
+
+extern "C" int lcao_injnorm_levels(int level, const float* a, const float* b, const float* g, const float* ha,
+                                   const float* hb, int64_t n_rows, int V, float eps, float* out0, float* out1, float* out2,
+                                   void* stream) {
+  if (n_rows < 0 || V <= 0 || level < 0 || level > 2) return LCAO_ERR_INVALID;
+  if (V > 512) return LCAO_ERR_UNSUPPORTED;
+  if (n_rows == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(a); LCAO_CHECK_PTR(b); LCAO_CHECK_PTR(out0);
+  if (level >= 1) { LCAO_CHECK_PTR(g); LCAO_CHECK_PTR(out1); }
+  if (level == 2) { LCAO_CHECK_PTR(ha); LCAO_CHECK_PTR(hb); LCAO_CHECK_PTR(out2); }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n_rows, 4, 65536)), block(256);
+  const int R = (V + 63) / 64;
+#define IN_L(RR, LV) hipLaunchKernelGGL((k_injnorm_levels<RR, LV>), grid, block, 0, st, a, b, g, ha, hb, n_rows, V, eps, out0, out1, out2)
+#define IN_R(RR) { if (level == 0) IN_L(RR, 0); else if (level == 1) IN_L(RR, 1); else IN_L(RR, 2); }
+  if (R == 1) IN_R(1) else if (R == 2) IN_R(2) else if (R <= 4) IN_R(4) else IN_R(8)
+#undef IN_R
+#undef IN_L
+  return lcao_launch_status();
+}
+
+extern "C" int lcao_silumul_levels(int level, const float* a, const float* x, const float* g, const float* ha,
+                                   const float* hx, int64_t n, float* out0, float* out1, float* out2, void* stream) {
+  if (n < 0 || n % 4 || level < 0 || level > 2) return LCAO_ERR_INVALID;
+  if (n == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(a); LCAO_CHECK_PTR(x); LCAO_CHECK_PTR(out0);
+  if (level >= 1) { LCAO_CHECK_PTR(g); LCAO_CHECK_PTR(out1); }
+  if (level == 2) { LCAO_CHECK_PTR(ha); LCAO_CHECK_PTR(hx); LCAO_CHECK_PTR(out2); }
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out0)) & 15) return LCAO_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n / 4, 256, 65536)), block(256);
+  if (level == 0) hipLaunchKernelGGL(k_silumul_levels<0>, grid, block, 0, st, a, x, g, ha, hx, n, out0, out1, out2);
+  else if (level == 1) hipLaunchKernelGGL(k_silumul_levels<1>, grid, block, 0, st, a, x, g, ha, hx, n, out0, out1, out2);
+  else hipLaunchKernelGGL(k_silumul_levels<2>, grid, block, 0, st, a, x, g, ha, hx, n, out0, out1, out2);
+  return lcao_launch_status();
+}

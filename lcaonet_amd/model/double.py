@@ -39,6 +39,9 @@ from ..data.keys import GraphKeys
 # first-level backwards skip the gradients of inputs that are functions of the parameters alone.
 # ---------------------------------------------------------------------------------------------------------------------
 _POS_ONLY = False
+# The fused maps with hand-written derivative levels (_ASideFn, ...) versus their composition from the smaller primitives —
+# the same function either way; tests switch this off to check one against the other.
+FUSED_LEVELS = True
 
 
 class positions_only:
@@ -317,6 +320,80 @@ class _ContractDtFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# the contraction TOGETHER with its consumers (gated copy, sum over l, Gram matrix) as one map with derivative levels:
+# A (E, n_l, V) and its gradient never exist as tensors (csrc/lcao_double.hip::k_aside rebuilds A from rb and the table)
+# ---------------------------------------------------------------------------------------------------------------------
+def _aside(level, geo, rb, T, gate, **kw):
+    c = geo.ctx
+    return ops.aside_levels(level, T, rb, geo.l_of_d, geo.z, c.src_p, c.dst_p, gate, geo.n_l, geo.zdim, **kw)
+
+
+def _aside_from_primitives(geo, rb, T, gate):
+    A = _ContractFn.apply(rb, T, geo)
+    Ag, B = _GateSumFn.apply(A.contiguous(), gather(gate, geo.src))
+    return Ag, B, _GramFn.apply(A.contiguous())
+
+
+class _ASideFn(Function):
+    """(rb, T, gate) -> (Ag, B, G)  with  A = contract(rb, T), Ag = A gate[src], B = sum_l A, G = A A^T."""
+
+    @staticmethod
+    def forward(ctx, rb, T, gate, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(rb, T, gate)
+        return _aside(0, geo, rb, T, gate)
+
+    @staticmethod
+    def backward(ctx, gAg, gB, gG):
+        rb, T, gate = ctx.saved_tensors
+        geo = ctx.geo
+        E, V, L = geo.E, T.shape[-1], geo.n_l
+        gAg = torch.zeros(E, L, V, device=rb.device) if gAg is None else gAg.contiguous()
+        gB = torch.zeros(E, V, device=rb.device) if gB is None else gB.contiguous()
+        gG = torch.zeros(E, L, L, device=rb.device) if gG is None else gG.contiguous()
+        if _POS_ONLY:                                       # the force pass: dE/drb and dE/dgate, differentiable again
+            g_rb, g_gate = _ASideBwdFn.apply(gAg, gB, gG, rb, T, gate, geo)
+            return g_rb, None, g_gate, None
+        if not torch.is_grad_enabled():                     # a plain backward: the fused level with the table gradient
+            g_rb, part, gA = _aside(1, geo, rb, T, gate, gAg=gAg, gB=gB, gG=gG, want_table_terms=True)
+            return g_rb, _c3(geo, gA, rb, V), ops.segment_sum(part, geo.src.ptr), None
+        # every gradient, with a graph: the primitives (each closed under differentiation) on the saved inputs
+        with torch.enable_grad():
+            outs = _aside_from_primitives(geo, rb, T, gate)
+            need = [i for i in range(3) if ctx.needs_input_grad[i]]
+            got = torch.autograd.grad(outs, [(rb, T, gate)[i] for i in need], (gAg, gB, gG), create_graph=True,
+                                      allow_unused=True)
+        res = [None, None, None, None]
+        for i, g in zip(need, got):
+            res[i] = g
+        return tuple(res)
+
+
+class _ASideBwdFn(Function):
+    @staticmethod
+    def forward(ctx, gAg, gB, gG, rb, T, gate, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(gAg, gB, gG, rb, T, gate)
+        g_rb, part = _aside(1, geo, rb, T, gate, gAg=gAg, gB=gB, gG=gG)
+        return g_rb, ops.segment_sum(part, geo.src.ptr)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h_rb, h_gate):
+        gAg, gB, gG, rb, T, gate = ctx.saved_tensors
+        geo = ctx.geo
+        h_rb = torch.zeros_like(rb) if h_rb is None else h_rb.contiguous()
+        h_gate = None if h_gate is None else h_gate.contiguous()
+        with_T = ctx.needs_input_grad[4]
+        out = _aside(2, geo, rb, T, gate, gAg=gAg, gB=gB, gG=gG, h_rb=h_rb, h_gate=h_gate, want_table_terms=with_T)
+        d_T = None
+        if with_T:
+            V = T.shape[-1]
+            d_T = _c3(geo, out[5], h_rb, V) + _c3(geo, out[6], rb, V)
+        return out[0], out[1], out[2], out[3], d_T, ops.segment_sum(out[4], geo.src.ptr), None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # three-body sum with explicit per-triplet weights (csrc/lcao_double.hip)
 # ---------------------------------------------------------------------------------------------------------------------
 class _SpmmFn(Function):
@@ -547,6 +624,40 @@ class _MulPBwdFn(Function):
         return dg, da, db, None
 
 
+def _two_operand_levels(op):
+    """(Fn, BwdFn) for a map f(a, b) whose `op(level, a, b, g, ha, hb)` gives f, (d/da, d/db) and the reverse sweep of that."""
+    class Fn(Function):
+        @staticmethod
+        def forward(ctx, a, b):
+            ctx.save_for_backward(a, b)
+            return op(0, a, b)
+
+        @staticmethod
+        def backward(ctx, g):
+            a, b = ctx.saved_tensors
+            return Bwd.apply(g.contiguous(), a, b)
+
+    class Bwd(Function):
+        @staticmethod
+        def forward(ctx, g, a, b):
+            ctx.save_for_backward(g, a, b)
+            return op(1, a, b, g)
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, ha, hb):
+            g, a, b = ctx.saved_tensors
+            ha = torch.zeros_like(a) if ha is None else ha.contiguous()
+            hb = torch.zeros_like(a) if hb is None else hb.contiguous()
+            return op(2, a, b, g, ha, hb)
+
+    return Fn, Bwd
+
+
+_InjNormFn, _InjNormBwdFn = _two_operand_levels(ops.injnorm_levels)      # F.normalize(B (1 + ft)), lcaonet.py:192-196
+_SiluMulFn, _SiluMulBwdFn = _two_operand_levels(ops.silumul_levels)      # bw * silu(.), lcaonet.py:209-211
+
+
 def mulp(a: Tensor, b: Tensor, c0: float) -> Tensor:
     return _MulPFn.apply(a.contiguous(), b.contiguous(), float(c0))
 
@@ -637,25 +748,37 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
             A, B, Bv = Ac + Av, Ac.sum(dim=1), Av.sum(dim=1)
             Ag = A * gather(gate, geo.src).unsqueeze(1)
         else:
-            A = _ContractFn.apply(rb, Tf, geo)
-            if V % 4 == 0:
-                Ag, B = _GateSumFn.apply(A.contiguous(), gather(gate, geo.src))
-            else:
-                Ag, B = A * gather(gate, geo.src).unsqueeze(1), A.sum(dim=1)
             Bv = None
-        G = _GramFn.apply(A.contiguous())
+            if V in ops.ASIDE_WIDTHS and FUSED_LEVELS:
+                Ag, B, G = _ASideFn.apply(rb, Tf.contiguous(), gate.contiguous(), geo)
+            else:
+                A = _ContractFn.apply(rb, Tf, geo)
+                if V % 4 == 0:
+                    Ag, B = _GateSumFn.apply(A.contiguous(), gather(gate, geo.src))
+                else:
+                    Ag, B = A * gather(gate, geo.src).unsqueeze(1), A.sum(dim=1)
+        if Bv is not None or not (V in ops.ASIDE_WIDTHS and FUSED_LEVELS):
+            G = _GramFn.apply(A.contiguous())
         tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)               # (e_own, V)
         ft = dense(tbw, layer.f_three[0].weight)
         B = B[: geo.e_own]
-        if Bv is None:
-            lw_in = mulp(B, ft, 1.0)                                          # B (1 + ft)
+        if Bv is None and FUSED_LEVELS:
+            lw = _InjNormFn.apply(B.contiguous(), ft.contiguous())            # F.normalize(B (1 + ft), dim=-1)
         else:
-            Bv = Bv[: geo.e_own]
-            lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
-        bw = dense(_RowNormFn.apply(lw_in.contiguous()), layer.basis_weight.weight)       # F.normalize(dim=-1)
+            if Bv is None:
+                lw_in = mulp(B, ft, 1.0)
+            else:
+                Bv = Bv[: geo.e_own]
+                lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
+            lw = _RowNormFn.apply(lw_in.contiguous())
+        bw = dense(lw, layer.basis_weight.weight)
         h1 = _activation(layer.f_node[1], _PairPreFn.apply(Ps.contiguous(), Pt.contiguous(), geo))
-        h2 = _activation(layer.f_node[3], dense(h1, layer.f_node[2].weight, layer.f_node[2].bias))
-        x = x[:n_own] + dense(scatter_sum(mulp(bw, h2, 0.0), geo.agg), layer.out_weight.weight)
+        pre2 = dense(h1, layer.f_node[2].weight, layer.f_node[2].bias)
+        if type(layer.f_node[3]) is torch.nn.SiLU and FUSED_LEVELS and V % 4 == 0:
+            msg = _SiluMulFn.apply(bw.contiguous(), pre2.contiguous())
+        else:
+            msg = mulp(bw, _activation(layer.f_node[3], pre2), 0.0)
+        x = x[:n_own] + dense(scatter_sum(msg, geo.agg), layer.out_weight.weight)
     prop = _mlp(model.out_layer.out_lin, x)
     batch = graph.get(GraphKeys.Batch_idx)
     ext = model.out_layer.is_extensive

@@ -930,6 +930,73 @@ def mulp_levels(level: int, a, b, c0: float, g=None, ha=None, hb=None):
     return outs[0] if level == 0 else tuple(outs)
 
 
+def _three_level_call(name, level, a, b, cots, extra):
+    a, b = _f32(a, "a"), _f32(b, "b")
+    ts = [None if t is None else _f32(t) for t in cots]
+    for t in [b] + [t for t in ts if t is not None]:
+        if t.shape != a.shape:
+            raise ValueError(f"{name}: operands must have one shape")
+    outs = [torch.empty_like(a) for _ in range(level + 1)]
+    opt = lambda t: _p(t) if t is not None else None
+    po = [_p(o) for o in outs] + [None] * (2 - level)
+    _call(name, level, _p(a), _p(b), opt(ts[0]), opt(ts[1]), opt(ts[2]), *extra(a), po[0], po[1], po[2], _stream())
+    return outs[0] if level == 0 else tuple(outs)
+
+
+def injnorm_levels(level: int, a, b, g=None, ha=None, hb=None, eps: float = 1e-12):
+    """F.normalize(a (1 + b), dim=-1) with derivative levels (csrc/lcao_double.hip::k_injnorm_levels): 0 -> y;
+    1 -> (d/da, d/db); 2 -> (d/dg, d/da, d/db)."""
+    V = a.shape[-1]
+    return _three_level_call("lcao_injnorm_levels", level, a, b, (g, ha, hb), lambda t: (t.numel() // max(V, 1), V, float(eps)))
+
+
+def silumul_levels(level: int, a, x, g=None, ha=None, hx=None):
+    """a * silu(x) with derivative levels (csrc/lcao_double.hip::k_silumul_levels): 0 -> m; 1 -> (d/da, d/dx);
+    2 -> (d/dg, d/da, d/dx).  numel % 4 == 0."""
+    return _three_level_call("lcao_silumul_levels", level, a, x, (g, ha, hx), lambda t: (t.numel(),))
+
+
+ASIDE_WIDTHS = (32, 64, 128)
+
+
+def aside_levels(level: int, Tf, rb, l_of_d, z, src_p, dst_p, gate, n_l: int, zdim: int, gAg=None, gB=None, gG=None,
+                 h_rb=None, h_gate=None, want_table_terms: bool = False):
+    """The orbital contraction with its consumers and its derivative levels (csrc/lcao_double.hip::k_aside):
+    0 -> (Ag, B, G);  1 -> (g_rb, g_gate_part[, gA]);  2 -> (d_gAg, d_gB, d_gG, d_rb, d_gate_part[, gA, dA])."""
+    Tf, rb, gate = _f32(Tf, "Tf"), _f32(rb, "rb"), _f32(gate, "gate")
+    E, D = rb.shape
+    V = Tf.shape[-1]
+    if Tf.shape[0] != zdim * zdim or Tf.shape[1] != D or gate.shape[1] != V:
+        raise ValueError("aside_levels: Tf (zdim^2, D, V), rb (E, D), gate (N, V)")
+    dev = rb.device
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    opt = lambda t: _p(t) if t is not None else None
+    if level >= 1:
+        gAg, gB, gG = _f32(gAg, "gAg"), _f32(gB, "gB"), _f32(gG, "gG")
+        if gAg.shape != (E, n_l, V) or gB.shape != (E, V) or gG.shape != (E, n_l, n_l):
+            raise ValueError("aside_levels: cotangents gAg (E, n_l, V), gB (E, V), gG (E, n_l, n_l)")
+    if level == 2:
+        h_rb = _f32(h_rb, "h_rb")
+        h_gate = None if h_gate is None else _f32(h_gate, "h_gate")
+        if h_rb.shape != (E, D) or (h_gate is not None and h_gate.shape != gate.shape):
+            raise ValueError("aside_levels: cotangents h_rb (E, D), h_gate (N, V)")
+    big0 = new(E, n_l, V) if level != 1 else None
+    row0 = new(E, V) if level != 1 else None
+    gram = new(E, n_l, n_l) if level != 1 else None
+    o_rb = new(E, D) if level >= 1 else None
+    row1 = new(E, V) if level >= 1 else None
+    o_gA = new(E, n_l, V) if (level >= 1 and want_table_terms) else None
+    o_dA = new(E, n_l, V) if (level == 2 and want_table_terms) else None
+    _call("lcao_aside_levels", level, _p(Tf), _p(rb), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate), opt(gAg), opt(gB),
+          opt(gG), opt(h_rb), opt(h_gate), E, D, V, n_l, zdim, opt(big0), opt(row0), opt(gram), opt(o_rb), opt(row1),
+          opt(o_gA), opt(o_dA), _stream())
+    if level == 0:
+        return big0, row0, gram
+    if level == 1:
+        return (o_rb, row1, o_gA) if want_table_terms else (o_rb, row1)
+    return (big0, row0, gram, o_rb, row1, o_gA, o_dA) if want_table_terms else (big0, row0, gram, o_rb, row1)
+
+
 def rownorm_levels(level: int, x, g=None, k=None, eps: float = 1e-12):
     """x / max(|x|, eps) along the last dim with closed-form derivatives; levels as silu_levels."""
     x = _f32(x, "x")

@@ -69,6 +69,39 @@ def test_exact_force_training_vs_oracle_double_backward(dev, case):
         assert int(m.emb_layer.coeff_embed.bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("V,n_int,training", [(32, 2, False), (64, 3, True), (128, 2, False)])
+def test_fused_levels_equal_their_composition_from_primitives(dev, V, n_int, training):
+    """The fused maps with hand-written derivative levels (double._ASideFn ...) against the same function assembled from
+    the smaller primitives (double.FUSED_LEVELS = False): energy, forces and every parameter gradient of an energy +
+    force loss (second derivatives), and the plain first-order gradients of an energy-only loss."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import double
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=V, n_interaction=n_int, cutoff=5.0, regress_forces=True,
+              direct_forces=False)
+    m, _ = _random_model(dev, 4242, grad=True, **kw)
+    m.train(training)
+    g = random_periodic_cells(3, 9, 6.0, 0.99 * 5.0, seed=77).to(dev)
+
+    def run(fused, energy_only):
+        double.FUSED_LEVELS = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            e, f = m(g)
+            loss = (e ** 2).mean() if energy_only else 0.1 * (e ** 2).mean() + ((f - 0.05) ** 2).mean()
+            loss.backward()
+            return e.detach(), f.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            double.FUSED_LEVELS = True
+
+    for energy_only in (False, True):
+        e1, f1, g1 = run(True, energy_only)
+        e0, f0, g0 = run(False, energy_only)
+        assert relerr(e1, e0) <= 2e-6 and relerr(f1, f0) <= 1e-5
+        assert g1.keys() == g0.keys() and len(g1) > 25
+        worst = max(relerr(g1[n], g0[n]) for n in g0 if float(g0[n].abs().max()) > 1e-12)
+        assert worst <= 2e-5, worst
+
+
 def test_eval_mode_forces_are_differentiable_and_match_the_inference_sweep(dev):
     """Eval mode with autograd on returns forces WITH a graph (the reference's create_graph=True), equal to the fast
     graph-less inference sweep (frozen parameters / torch.no_grad()); the force graph reaches pos-independent parameters
@@ -326,6 +359,71 @@ def test_product_primitives_first_and_second_derivatives(dev):
     got = chain(lambda x, y: _PairPreFn.apply(x, y, geo), [Ps, Pt], R, Hs)
     want = chain(lambda x, y: x[geo.src.idx] + y[geo.dst.idx], dbl([Ps, Pt]), dbl(R), dbl(Hs))
     assert all(relerr(g_, w) <= 2e-6 for g_, w in zip(got, want))
+
+
+def test_fused_level_maps_first_and_second_derivatives(dev):
+    """model/double.py _InjNormFn (F.normalize(a (1 + b))), _SiluMulFn (a silu(x)) and _ASideFn (contraction + gated copy +
+    sum over l + Gram matrix; first level restricted to rb and gate as in the force pass): value, gradient and
+    gradient-of-gradient against the same expressions from fp64 tensor ops under autograd."""
+    import torch.nn.functional as F
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    from lcaonet_amd.model import LCAONet, double
+    from lcaonet_amd.model.double import _ASideFn, _Geo, _InjNormFn, _SiluMulFn
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda *shape: torch.randn(*shape, generator=gen).to(dev)
+
+    def chain(f, inputs, R, Hs, first=None):
+        xs = [x.clone().requires_grad_(True) for x in inputs]
+        Rr = [r.clone().requires_grad_(True) for r in R]
+        outs = f(*xs)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        wrt = xs if first is None else [xs[i] for i in first]
+        g1 = torch.autograd.grad(sum((o * r).sum() for o, r in zip(outs, Rr)), wrt, create_graph=True)
+        g2 = torch.autograd.grad(sum((g * h).sum() for g, h in zip(g1, Hs)), xs + Rr, allow_unused=True)
+        g2 = [torch.zeros_like(t) if g is None else g for g, t in zip(g2, xs + Rr)]
+        return [o.detach() for o in outs] + [g.detach() for g in g1] + list(g2)
+    dbl = lambda ts: [t.double() for t in ts]
+    for E, V in ((5, 16), (700, 128), (33, 48), (9, 200)):
+        a, b = rnd(E, V), 0.5 * rnd(E, V)
+        a[1] = 0.0                                                       # a row at the clamp of F.normalize
+        R, Hs = [rnd(E, V)], [rnd(E, V), rnd(E, V)]
+        got = chain(lambda x, y: _InjNormFn.apply(x, y), [a, b], R, Hs)
+        want = chain(lambda x, y: F.normalize(x * (1 + y), dim=-1), dbl([a, b]), dbl(R), dbl(Hs))
+        keep = torch.ones(E, dtype=torch.bool, device=dev)
+        keep[1] = False                                                  # the clamped row: value and first level only
+        for i, (g_, w_) in enumerate(zip(got, want)):
+            assert relerr(g_[keep], w_[keep]) <= 5e-6, ("injnorm", E, V, i, relerr(g_[keep], w_[keep]))
+        assert float(got[0][1].abs().max()) == 0.0
+        got = chain(lambda x, y: _SiluMulFn.apply(x, y), [a, b], R, Hs)
+        want = chain(lambda x, y: x * F.silu(y), dbl([a, b]), dbl(R), dbl(Hs))
+        assert all(relerr(g_, w_) <= 5e-6 for g_, w_ in zip(got, want)), ("silumul", E, V)
+    for V, max_z in ((32, 10), (64, 36), (128, 36), (64, 2)):            # n_l = 2, 3, 3, 1
+        g = random_periodic_cells(2, 11, 6.0, 0.99 * 4.5, seed=3, max_z=max_z).to(dev)
+        m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=V, n_interaction=1, cutoff=4.5, max_z=max_z).to(dev)
+        geo = _Geo(m, g)
+        D, L = len(geo.l_of_d), geo.n_l
+        rb, T, gate = rnd(geo.E, D), 0.3 * rnd(geo.zdim ** 2, D, V), rnd(geo.N, V)
+        R = [rnd(geo.E, L, V), rnd(geo.E, V), rnd(geo.E, L, L)]
+        Hs = [rnd(geo.E, D), rnd(geo.N, V)]
+        lod = geo.l_of_d.long()
+        pair = (geo.z[geo.src.idx] * geo.zdim + geo.z[geo.dst.idx])
+
+        def literal(rb_, T_, gate_):
+            onehot = torch.zeros(D, L, dtype=rb_.dtype, device=dev)
+            onehot[torch.arange(D, device=dev), lod] = 1
+            A = torch.einsum("pd,pdv,dl->plv", rb_, T_[pair], onehot)
+            return A * gate_[geo.src.idx].unsqueeze(1), A.sum(1), torch.einsum("plv,pmv->plm", A, A)
+        # first level restricted to (rb, gate) as in the force pass; second level w.r.t. everything
+        xs = [t.clone().requires_grad_(True) for t in (rb, T, gate)]
+        Rr = [r.clone().requires_grad_(True) for r in R]
+        with double.positions_only():
+            g1 = torch.autograd.grad(sum((o * r).sum() for o, r in zip(_ASideFn.apply(*xs, geo), Rr)), [xs[0], xs[2]],
+                                     create_graph=True)
+        g2 = torch.autograd.grad(sum((a_ * h).sum() for a_, h in zip(g1, Hs)), xs + Rr)
+        got = [t.detach() for t in _ASideFn.apply(rb, T, gate, geo)] + [t.detach() for t in g1] + list(g2)
+        want = chain(literal, dbl([rb, T, gate]), dbl(R), dbl(Hs), first=(0, 2))
+        for i, (g_, w_) in enumerate(zip(got, want)):
+            assert relerr(g_, w_) <= 1e-5, ("aside", V, i, relerr(g_, w_))
 
 
 def test_rowgram_family_first_and_second_derivatives(dev):
