@@ -143,6 +143,13 @@ __global__ void k_trip_sddmm(const float* __restrict__ G, const float* __restric
 // Rows / columns past the node's extents are clamped duplicates (computed, never stored); only the K dimension is
 // zero-padded.
 // ---------------------------------------------------------------------------------------------------------------------
+// Common shape of the three: the out-list of a node (m_out rows, 18 in a crystal) is covered by PAIRS of 16-row tiles
+// that share every load of the long operand (the in-edge rows A, m_in n_l of them), and the loads of step k + 1 are issued
+// before the MFMAs of step k — one wave per node has nothing else to hide a gather behind.
+//
+// four consecutive floats at a 4-byte aligned address (one global_load/store_dwordx4: gfx950 runs with unaligned access on)
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };
+
 // sddmm: D[m = (j,l)][i] = sum_v A[q_j, l, v] G[p_i, v];  k = 16 kk + 4 q + c for MFMA step c of chunk kk (both operands)
 template <int NL>
 __global__ __launch_bounds__(256) void k_trip_sddmm_node(const float* __restrict__ G, const float* __restrict__ A,
@@ -154,14 +161,17 @@ __global__ __launch_bounds__(256) void k_trip_sddmm_node(const float* __restrict
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int nwave = (gridDim.x * blockDim.x) >> 6;
   const int KC = (V + 15) >> 4;
+  const f32x4v z = {0.f, 0.f, 0.f, 0.f};
   for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_nodes; s += nwave) {
     const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
     const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
     if (m_out <= 0 || m_in <= 0) continue;
     const int Mtot = m_in * NL;
     const int64_t t0 = tbase[s];
-    for (int i0 = 0; i0 < m_out; i0 += 16) {
-      const float* gb = G + (int64_t)(p0 + min(i0 + r, m_out - 1)) * V + 4 * q;
+    for (int i0 = 0; i0 < m_out; i0 += 32) {
+      const bool two = m_out - i0 > 16;
+      const float* gb0 = G + (int64_t)(p0 + min(i0 + r, m_out - 1)) * V + 4 * q;
+      const float* gb1 = G + (int64_t)(p0 + min(i0 + 16 + r, m_out - 1)) * V + 4 * q;
       for (int m0 = 0; m0 < Mtot; m0 += 64) {
         const int ntile = min(4, (Mtot - m0 + 15) >> 4);
         const float* ab[4];
@@ -170,34 +180,59 @@ __global__ __launch_bounds__(256) void k_trip_sddmm_node(const float* __restrict
           const int m = min(m0 + 16 * t + r, Mtot - 1);
           ab[t] = A + ((int64_t)in_pos[j0 + m / NL] * NL + m % NL) * V + 4 * q;
         }
-        f32x4v acc[4];
+        f32x4v acc[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) { acc[0][t] = z; acc[1][t] = z; }
+        f32x4v a[4], b0, b1;
+        {
+          const bool ok = 4 * q < V;
+          b0 = ok ? *(const f32x4v*)gb0 : z;
+          b1 = (ok && two) ? *(const f32x4v*)gb1 : z;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a[t] = (ok && t < ntile) ? *(const f32x4v*)ab[t] : z;
+        }
+#pragma unroll 1
         for (int kk = 0; kk < KC; ++kk) {
-          const bool ok = 16 * kk + 4 * q < V;
-          const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-          const f32x4v b = ok ? *(const f32x4v*)(gb + 16 * kk) : z;
-          f32x4v a[4];
+          f32x4v na[4], nb0 = z, nb1 = z;
+          const bool ok = kk + 1 < KC && 16 * (kk + 1) + 4 * q < V;
+          nb0 = ok ? *(const f32x4v*)(gb0 + 16 * (kk + 1)) : z;
+          nb1 = (ok && two) ? *(const f32x4v*)(gb1 + 16 * (kk + 1)) : z;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) a[t] = (ok && t < ntile) ? *(const f32x4v*)(ab[t] + 16 * kk) : z;
+          for (int t = 0; t < 4; ++t) na[t] = (ok && t < ntile) ? *(const f32x4v*)(ab[t] + 16 * (kk + 1)) : z;
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              if (t < ntile) acc[t] = MFMA16(a[t][c], b[c], acc[t]);
+              if (t < ntile) {
+                acc[0][t] = MFMA16(a[t][c], b0[c], acc[0][t]);
+                if (two) acc[1][t] = MFMA16(a[t][c], b1[c], acc[1][t]);
+              }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a[t] = na[t];
+          b0 = nb0;
+          b1 = nb1;
         }
-        if (i0 + r < m_out) {
-          float* o = out + (t0 + (int64_t)(i0 + r) * m_in) * NL;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int m = m0 + 16 * t + 4 * q;
-            if (t < ntile) {
-              if (NL == 4) {
-                if (m < Mtot) *(f32x4v*)(o + m) = acc[t];
-              } else {
+        for (int h = 0; h < 2; ++h) {
+          const int i = i0 + 16 * h + r;
+          if (i < m_out) {
+            float* o = out + (t0 + (int64_t)i * m_in) * NL;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                  if (m + jj < Mtot) o[m + jj] = acc[t][jj];
+            for (int t = 0; t < 4; ++t) {
+              const int m = m0 + 16 * t + 4 * q;
+              if (t < ntile) {
+                if (NL == 4) {
+                  if (m < Mtot) *(f32x4v*)(o + m) = acc[h][t];
+                } else if (m + 4 <= Mtot) {
+                  F4U y;
+#pragma unroll
+                  for (int jj = 0; jj < 4; ++jj) y.v[jj] = acc[h][t][jj];
+                  *(F4U*)(o + m) = y;
+                } else {
+#pragma unroll
+                  for (int jj = 0; jj < 4; ++jj)
+                    if (m + jj < Mtot) o[m + jj] = acc[h][t][jj];
+                }
               }
             }
           }
@@ -207,7 +242,9 @@ __global__ __launch_bounds__(256) void k_trip_sddmm_node(const float* __restrict
   }
 }
 
-// spmm: D_cc[4r' .. ][i] with row r of tile cc <-> channel v0 + 4 r + cc;  k = (j,l) = 16 kk + 4 q + c
+// spmm: D_cc[4r' .. ][i] with row r of tile cc <-> channel v0 + 4 r + cc;  k = (j,l) = 16 kk + 4 q + c.  The row offsets of
+// the k index (in_pos lookups) sit in a per-wave LDS table, so that a step's gathers do not wait for an index load first.
+#define TRIP_ROWTAB 256
 template <int NL>
 __global__ __launch_bounds__(256) void k_trip_spmm_node(const float* __restrict__ w, const float* __restrict__ A,
                                                         const int32_t* __restrict__ in_ptr,
@@ -215,56 +252,82 @@ __global__ __launch_bounds__(256) void k_trip_spmm_node(const float* __restrict_
                                                         const int32_t* __restrict__ out_ptr,
                                                         const int64_t* __restrict__ tbase, int n_nodes, int V,
                                                         float* __restrict__ out) {
+  __shared__ int rowtab_all[4][TRIP_ROWTAB];
+  int* rowtab = rowtab_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int nwave = (gridDim.x * blockDim.x) >> 6;
-  for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_nodes; s += nwave) {
+  const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+  const int NV = (V + 63) >> 6;                            // one wave per (node, 64-channel chunk)
+  for (int ws = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; ws < n_nodes * NV; ws += nwave) {
+    const int s = ws / NV, v0 = 64 * (ws - s * NV);
     const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
     const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
     if (m_out <= 0) continue;
     const int Ktot = m_in * NL, KC = (Ktot + 15) >> 4;
     const int64_t t0 = tbase[s];
-    for (int i0 = 0; i0 < m_out; i0 += 16) {
-      const float* wb = w + (t0 + (int64_t)min(i0 + r, m_out - 1) * m_in) * NL;
-      for (int v0 = 0; v0 < V; v0 += 64) {
+    __builtin_amdgcn_wave_barrier();                       // the previous node's reads of the tables are done (in-order LDS)
+    for (int k = lane; k < min(Ktot, TRIP_ROWTAB); k += 64) rowtab[k] = in_pos[j0 + k / NL] * NL + k % NL;
+    __builtin_amdgcn_wave_barrier();
+    auto row_of = [&](int k) -> int64_t {                  // k < Ktot
+      return k < TRIP_ROWTAB ? rowtab[k] : in_pos[j0 + k / NL] * NL + k % NL;
+    };
+    for (int i0 = 0; i0 < m_out; i0 += 32) {
+      const bool two = m_out - i0 > 16;
+      const float* wb0 = w + (t0 + (int64_t)min(i0 + r, m_out - 1) * m_in) * NL;
+      const float* wb1 = w + (t0 + (int64_t)min(i0 + 16 + r, m_out - 1) * m_in) * NL;
+      {
         const int vld = (v0 + 4 * r < V) ? v0 + 4 * r : 0;
-        f32x4v acc[4];
+        f32x4v acc[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        for (int kk = 0; kk < KC; ++kk) {
+        for (int t = 0; t < 4; ++t) { acc[0][t] = z; acc[1][t] = z; }
+        f32x4v a[4], b0, b1;
+        auto load = [&](int kk, f32x4v (&aa)[4], f32x4v& bb0, f32x4v& bb1) {
           const int k = 16 * kk + 4 * q;
-          f32x4v b, a[4];
-          if (NL == 4) {
-            b = k < Ktot ? *(const f32x4v*)(wb + k) : f32x4v{0.f, 0.f, 0.f, 0.f};
-            const float* ar = A + (int64_t)in_pos[j0 + min(k >> 2, m_in - 1)] * 4 * V + vld;
+          if (NL == 4 || k + 4 <= Ktot) {                  // rows of w start at any 4-byte boundary when n_l != 4
+            const F4U x0 = *(const F4U*)(wb0 + k), x1 = *(const F4U*)(wb1 + k);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a[c] = *(const f32x4v*)(ar + c * V);
+            for (int c = 0; c < 4; ++c) { bb0[c] = x0.v[c]; bb1[c] = x1.v[c]; }
+            if (NL == 4 && k >= Ktot) { bb0 = z; bb1 = z; }
           } else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              b[c] = k + c < Ktot ? wb[k + c] : 0.f;
-              const int kc = min(k + c, Ktot - 1);
-              a[c] = *(const f32x4v*)(A + ((int64_t)in_pos[j0 + kc / NL] * NL + kc % NL) * V + vld);
+              const bool in = k + c < Ktot;
+              bb0[c] = in ? wb0[k + c] : 0.f;
+              bb1[c] = in ? wb1[k + c] : 0.f;
             }
           }
 #pragma unroll
+          for (int c = 0; c < 4; ++c) aa[c] = *(const f32x4v*)(A + row_of(min(k + c, Ktot - 1)) * V + vld);
+        };
+        for (int kk = 0; kk < KC; ++kk) {
+          load(kk, a, b0, b1);
+#pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[c][t], b[c], acc[t]);
+            for (int t = 0; t < 4; ++t) {
+              acc[0][t] = MFMA16(a[c][t], b0[c], acc[0][t]);
+              if (two) acc[1][t] = MFMA16(a[c][t], b1[c], acc[1][t]);
+            }
         }
-        if (i0 + r < m_out) {
-          float* o = out + (int64_t)(p0 + i0 + r) * V;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int v = v0 + 16 * q + 4 * jj;
-            if (v < V) *(f32x4v*)(o + v) = f32x4v{acc[0][jj], acc[1][jj], acc[2][jj], acc[3][jj]};
+        for (int h = 0; h < 2; ++h)
+          if (i0 + 16 * h + r < m_out) {
+            float* o = out + (int64_t)(p0 + i0 + 16 * h + r) * V;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int v = v0 + 16 * q + 4 * jj;
+              if (v < V) *(f32x4v*)(o + v) = f32x4v{acc[h][0][jj], acc[h][1][jj], acc[h][2][jj], acc[h][3][jj]};
+            }
           }
-        }
       }
     }
   }
 }
 
-// spmm_t: D_cc[v][n = (j,l)] = sum_i G[p_i, v] w[t(i,j), l];  k = i = 4 ks + q (no permutation: K is the short out-list)
+// spmm_t: D_t[v][n = (j,l)] = sum_i G[p_i, v] w[t(i,j), l];  k = i = 4 ks + q (no permutation: K is the short out-list).
+// Row r of tile t <-> channel v0 + 16 t + r (scalar loads of the few, cache-resident G rows), so that a lane's four
+// accumulator rows are 16 consecutive bytes and the four lanes of a column write one whole 64-byte line per store.
+// Two column tiles (32 of the m_in n_l columns) share the loads of the G rows.
 template <int NL>
 __global__ __launch_bounds__(256) void k_trip_spmm_t_node(const float* __restrict__ w, const float* __restrict__ G,
                                                           const int32_t* __restrict__ in_ptr,
@@ -274,36 +337,60 @@ __global__ __launch_bounds__(256) void k_trip_spmm_t_node(const float* __restric
                                                           float* __restrict__ out) {
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int nwave = (gridDim.x * blockDim.x) >> 6;
+  const f32x4v z = {0.f, 0.f, 0.f, 0.f};
   for (int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; s < n_nodes; s += nwave) {
     const int p0 = out_ptr[s], m_out = out_ptr[s + 1] - p0;
     const int j0 = in_ptr[s], m_in = in_ptr[s + 1] - j0;
     if (m_in <= 0) continue;
     const int Ntot = m_in * NL, KS = (m_out + 3) >> 2;
     const int64_t t0 = tbase[s];
-    for (int n0 = 0; n0 < Ntot; n0 += 16) {
-      const int n = min(n0 + r, Ntot - 1);
-      const float* wb = w + t0 * NL + n;
-      const int64_t orow = (int64_t)in_pos[j0 + n / NL] * NL + n % NL;
+    for (int n0 = 0; n0 < Ntot; n0 += 32) {
+      const bool two = Ntot - n0 > 16;
+      const int na_ = min(n0 + r, Ntot - 1), nb_ = min(n0 + 16 + r, Ntot - 1);
+      const float* wb0 = w + t0 * NL + na_;
+      const float* wb1 = w + t0 * NL + nb_;
+      const int64_t orow0 = (int64_t)in_pos[j0 + na_ / NL] * NL + na_ % NL;
+      const int64_t orow1 = (int64_t)in_pos[j0 + nb_ / NL] * NL + nb_ % NL;
       for (int v0 = 0; v0 < V; v0 += 64) {
-        const int vld = (v0 + 4 * r < V) ? v0 + 4 * r : 0;
-        f32x4v acc[4];
+        f32x4v acc[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int t = 0; t < 4; ++t) { acc[0][t] = z; acc[1][t] = z; }
+        auto load = [&](int ks, f32x4v& aa, float& bb0, float& bb1) {
           const int i = 4 * ks + q;
-          const float b = i < m_out ? wb[(int64_t)i * Ntot] : 0.f;
-          const f32x4v a = *(const f32x4v*)(G + (int64_t)(p0 + min(i, max(m_out - 1, 0))) * V + vld);
+          const bool in = i < m_out;
+          bb0 = in ? wb0[(int64_t)i * Ntot] : 0.f;
+          bb1 = (in && two) ? wb1[(int64_t)i * Ntot] : 0.f;
+          const float* gr = G + (int64_t)(p0 + min(i, max(m_out - 1, 0))) * V + v0 + r;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = MFMA16(a[t], b, acc[t]);
-        }
-        if (n0 + r < Ntot) {
-          float* o = out + orow * V;
+          for (int t = 0; t < 4; ++t) aa[t] = (v0 + 16 * t + r < V) ? gr[16 * t] : 0.f;
+        };
+        f32x4v a = z;
+        float b0 = 0.f, b1 = 0.f;
+        if (KS > 0) load(0, a, b0, b1);
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+          f32x4v na = z;
+          float nb0 = 0.f, nb1 = 0.f;
+          if (ks + 1 < KS) load(ks + 1, na, nb0, nb1);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int v = v0 + 16 * q + 4 * jj;
-            if (v < V) *(f32x4v*)(o + v) = f32x4v{acc[0][jj], acc[1][jj], acc[2][jj], acc[3][jj]};
+          for (int t = 0; t < 4; ++t) {
+            acc[0][t] = MFMA16(a[t], b0, acc[0][t]);
+            if (two) acc[1][t] = MFMA16(a[t], b1, acc[1][t]);
           }
+          a = na;
+          b0 = nb0;
+          b1 = nb1;
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (n0 + 16 * h + r < Ntot) {
+            float* o = out + (h ? orow1 : orow0) * V;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int v = v0 + 16 * t + 4 * q;
+              if (v < V) *(f32x4v*)(o + v) = acc[h][t];
+            }
+          }
       }
     }
   }
@@ -849,9 +936,10 @@ static int check_trip(int64_t n_edges, int V, int n_l) {
     else hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, st, __VA_ARGS__);                \
   } while (0)
 
-#define NODE_DISPATCH(KERNEL, ...)                                                                     \
+#define NODE_DISPATCH(KERNEL, ...) NODE_DISPATCH_N(KERNEL, n_centres, __VA_ARGS__)
+#define NODE_DISPATCH_N(KERNEL, N_WAVES, ...)                                                          \
   do {                                                                                                 \
-    dim3 grid(lcao_blocks(n_centres, 4, 65536)), block(256);                                           \
+    dim3 grid(lcao_blocks((N_WAVES), 4, 65536)), block(256);                                           \
     if (n_l == 1) hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, st, __VA_ARGS__);                    \
     else if (n_l == 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, st, __VA_ARGS__);               \
     else if (n_l == 3) hipLaunchKernelGGL((KERNEL<3>), grid, block, 0, st, __VA_ARGS__);               \
@@ -873,7 +961,7 @@ extern "C" int lcao_trip_spmm(const float* w, const float* A, const int32_t* src
   LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(out);
   hipStream_t st = (hipStream_t)stream;
   if (V % 4 == 0 && n_centres > 0)
-    NODE_DISPATCH(k_trip_spmm_node, w, A, in_ptr, in_pos, out_ptr, tbase, (int)n_centres, V, out);
+    NODE_DISPATCH_N(k_trip_spmm_node, n_centres * ((V + 63) / 64), w, A, in_ptr, in_pos, out_ptr, tbase, (int)n_centres, V, out);
   else
     TRIP_DISPATCH(k_trip_spmm, w, A, src_p, in_ptr, in_pos, out_ptr, tbase, n_edges, V, n_l, out);
   return lcao_launch_status();

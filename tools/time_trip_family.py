@@ -1,0 +1,61 @@
+"""Time the three-body bilinear family (lcao_trip_spmm / spmm_t / sddmm, NL = n_l and the cosine form NL = 1) and the other
+force-training primitives on the cfg2 batch shape.      python tools/time_trip_family.py [--n-cells 1000] [--iters 10]"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from lcaonet_amd import ops  # noqa: E402
+from lcaonet_amd.data.synthetic import jittered_cubic_cells  # noqa: E402
+from lcaonet_amd.model.double import _Geo  # noqa: E402
+
+
+def timed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-cells", type=int, default=1000)
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    gen_kw, model_kw = bench.WORKLOADS["cfg2"]
+    batch = jittered_cubic_cells(seed=1234, device=dev, **dict(gen_kw, n_cells=args.n_cells))
+    m = bench.build_model(model_kw, 1234, dev)
+    geo = _Geo(m, batch)
+    E, T, V, L = geo.E, geo.T, 128, geo.n_l
+    print(f"E {E}  T {T}  n_l {L}  V {V}")
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    w, A, G = rnd(T, L), rnd(E, L, V), rnd(E, V)
+    w1, u4 = rnd(T, 1), rnd(E, 1, 4)
+    gb = lambda n_bytes, ms: n_bytes / ms / 1e6
+    rows = [
+        ("spmm   (w, A) -> (E,V)", lambda: ops.trip_spmm(w, A, geo), 4 * (T * L + E * L * V + E * V)),
+        ("spmm_t (w, G) -> (E,L,V)", lambda: ops.trip_spmm_t(w, G, geo), 4 * (T * L + E * V + E * L * V)),
+        ("sddmm  (G, A) -> (T,L)", lambda: ops.trip_sddmm(G, A, geo), 4 * (T * L + E * V + E * L * V)),
+        ("spmm   cos", lambda: ops.trip_spmm(w1, u4, geo), 4 * (T + 8 * E)),
+        ("spmm_t cos", lambda: ops.trip_spmm_t(w1, u4[:, 0], geo), 4 * (T + 8 * E)),
+        ("sddmm  cos", lambda: ops.trip_sddmm(u4[:, 0], u4, geo), 4 * (T + 8 * E)),
+    ]
+    for name, fn, nbytes in rows:
+        ms = timed(fn, args.iters)
+        print(f"{name:28s} {ms:8.3f} ms   {gb(nbytes, ms):8.0f} GB/s algorithmic")
+
+
+if __name__ == "__main__":
+    main()
