@@ -467,6 +467,14 @@ int lcao_injnorm_levels(int level, const float* a, const float* b, const float* 
 int lcao_silumul_levels(int level, const float* a, const float* x, const float* g, const float* ha, const float* hx,
                         int64_t n, float* out0, float* out1, float* out2, void* stream);
 
+/* h1[p,:] = silu(Ps[src_p[p]] + Pt[dst_p[p]])  (first layer of f_node on the pair, lcaonet.py:142-150) with derivative
+ * levels; the (E, V) pre-activation is rebuilt from the node tables Ps, Pt (N, V) at every level.  Level 0: out0 = h1;
+ * level 1 (cotangent g (E, V)): out0 = dE/dpre (E, V) — the caller's segment sums over src / dst give dE/dPs, dE/dPt;
+ * level 2 (cotangents hPs, hPt (N, V) of those sums): out0 = d/dg, out1 = d/dpre.  V % 4 == 0. */
+int lcao_pairsilu_levels(int level, const float* Ps, const float* Pt, const int32_t* src_p, const int32_t* dst_p,
+                         const float* g, const float* hPs, const float* hPt, int64_t n_edges, int V, float* out0,
+                         float* out1, void* stream);
+
 /* The gated copy Ag = A * gate[src] (lcaonet.py:186, broadcast over l) and B = sum_l A (:200-203) with the terms of their two
  * derivative levels:  bcast_fma: out[e,l,:] = X1[e,l,:] y1[e,:] (+ X2[e,l,:] y2[e,:]) (+ z[e,:]);
  *                     lsum_mul : out[e,:] = sum_l X[e,l,:] (Y[e,l,:] or 1).   X (E, L, V), y / z / out (E, V); V % 4 == 0. */

@@ -1552,3 +1552,61 @@ extern "C" int lcao_silumul_levels(int level, const float* a, const float* x, co
   else hipLaunchKernelGGL(k_silumul_levels<2>, grid, block, 0, st, a, x, g, ha, hx, n, out0, out1, out2);
   return lcao_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pairsilu (lcaonet.py:142-150, first layer of f_node on the pair): h1[p,:] = silu(Ps[src(p)] + Pt[dst(p)]) — the
+// pre-activation (E, V) is rebuilt from the two node tables at every level instead of being stored:
+//   level 0: out0 = silu(pre)
+//   level 1 (cotangent g of h1): out0 = g s1(pre)           — its segment sums over src / dst are dE/dPs, dE/dPt
+//   level 2 (cotangents hPs, hPt (N, V) of those sums): k = hPs[src] + hPt[dst];  out0 = k s1 [d/dg],  out1 = k g s2
+//            — the segment sums of out1 are d/dPs, d/dPt
+// One float4 of channels per thread; V % 4 == 0.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int LEVEL>
+__global__ void k_pairsilu_levels(const float* __restrict__ Ps, const float* __restrict__ Pt,
+                                  const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p,
+                                  const float* __restrict__ g, const float* __restrict__ hPs, const float* __restrict__ hPt,
+                                  int64_t n_edges, int V4, float* __restrict__ o0, float* __restrict__ o1) {
+  const int64_t total = n_edges * V4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t e = i / V4;
+    const int c = (int)(i - e * V4);
+    const int64_t so = ((int64_t)src_p[e] * V4 + c) * 4, to = ((int64_t)dst_p[e] * V4 + c) * 4;
+    const f32x4v x = *(const f32x4v*)(Ps + so) + *(const f32x4v*)(Pt + to);
+    const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4v gv = LEVEL >= 1 ? *(const f32x4v*)(g + i * 4) : z4;
+    const f32x4v kv = LEVEL == 2 ? *(const f32x4v*)(hPs + so) + *(const f32x4v*)(hPt + to) : z4;
+    f32x4v r0, r1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sg = 1.0f / (1.0f + __expf(-x[j]));
+      const float s1 = sg * (1.0f + x[j] * (1.0f - sg));
+      if (LEVEL == 0) r0[j] = x[j] * sg;
+      if (LEVEL == 1) r0[j] = gv[j] * s1;
+      if (LEVEL == 2) {
+        r0[j] = kv[j] * s1;
+        r1[j] = kv[j] * gv[j] * (sg * (1.0f - sg) * (2.0f + x[j] * (1.0f - 2.0f * sg)));
+      }
+    }
+    *(f32x4v*)(o0 + i * 4) = r0;
+    if (LEVEL == 2) *(f32x4v*)(o1 + i * 4) = r1;
+  }
+}
+
+extern "C" int lcao_pairsilu_levels(int level, const float* Ps, const float* Pt, const int32_t* src_p, const int32_t* dst_p,
+                                    const float* g, const float* hPs, const float* hPt, int64_t n_edges, int V,
+                                    float* out0, float* out1, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  if (level < 0 || level > 2 || V <= 0 || V % 4) return LCAO_ERR_INVALID;
+  if (n_edges == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(out0);
+  if (level >= 1) LCAO_CHECK_PTR(g);
+  if (level == 2) { LCAO_CHECK_PTR(hPs); LCAO_CHECK_PTR(hPt); LCAO_CHECK_PTR(out1); }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n_edges * (V / 4), 256, 65536)), block(256);
+  if (level == 0) hipLaunchKernelGGL(k_pairsilu_levels<0>, grid, block, 0, st, Ps, Pt, src_p, dst_p, g, hPs, hPt, n_edges, V / 4, out0, out1);
+  else if (level == 1) hipLaunchKernelGGL(k_pairsilu_levels<1>, grid, block, 0, st, Ps, Pt, src_p, dst_p, g, hPs, hPt, n_edges, V / 4, out0, out1);
+  else hipLaunchKernelGGL(k_pairsilu_levels<2>, grid, block, 0, st, Ps, Pt, src_p, dst_p, g, hPs, hPt, n_edges, V / 4, out0, out1);
+  return lcao_launch_status();
+}

@@ -591,6 +591,49 @@ class _PairPreFn(Function):
         return scatter_sum(g, ctx.geo.src_o), scatter_sum(g, ctx.geo.dst_o), None
 
 
+class _PairSiluFn(Function):
+    """h1 = silu(Ps[src] + Pt[dst]) on the owned out-edges (csrc/lcao_double.hip::k_pairsilu_levels): the pre-activation
+    is never stored; the adjoints to the node tables are sorted-segment sums inside the backward Function."""
+
+    @staticmethod
+    def forward(ctx, Ps, Pt, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(Ps, Pt)
+        c = geo.ctx
+        return ops.pairsilu_levels(0, Ps, Pt, c.src_p[: geo.e_own], c.dst_p[: geo.e_own])
+
+    @staticmethod
+    def backward(ctx, g):
+        Ps, Pt = ctx.saved_tensors
+        gPs, gPt = _PairSiluBwdFn.apply(g.contiguous(), Ps, Pt, ctx.geo)
+        return gPs, gPt, None
+
+
+def _to_node_tables(rows, geo):
+    return (ops.segment_sum_gather(rows, geo.src_o.perm, geo.src_o.ptr),
+            ops.segment_sum_gather(rows, geo.dst_o.perm, geo.dst_o.ptr))
+
+
+class _PairSiluBwdFn(Function):
+    @staticmethod
+    def forward(ctx, g, Ps, Pt, geo):
+        ctx.geo = geo
+        ctx.save_for_backward(g, Ps, Pt)
+        c = geo.ctx
+        return _to_node_tables(ops.pairsilu_levels(1, Ps, Pt, c.src_p[: geo.e_own], c.dst_p[: geo.e_own], g=g), geo)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hPs, hPt):
+        g, Ps, Pt = ctx.saved_tensors
+        geo, c = ctx.geo, ctx.geo.ctx
+        hPs = torch.zeros_like(Ps) if hPs is None else hPs.contiguous()
+        hPt = torch.zeros_like(Pt) if hPt is None else hPt.contiguous()
+        dg, dpre = ops.pairsilu_levels(2, Ps, Pt, c.src_p[: geo.e_own], c.dst_p[: geo.e_own], g=g, hPs=hPs, hPt=hPt)
+        dPs, dPt = _to_node_tables(dpre, geo)
+        return dg, dPs, dPt, None
+
+
 class _MulPFn(Function):
     """a (c0 + b) elementwise (csrc/lcao_double.hip::k_mulp_levels) with its first and second derivatives as single kernels."""
 
@@ -772,7 +815,10 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
                 lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
             lw = _RowNormFn.apply(lw_in.contiguous())
         bw = dense(lw, layer.basis_weight.weight)
-        h1 = _activation(layer.f_node[1], _PairPreFn.apply(Ps.contiguous(), Pt.contiguous(), geo))
+        if type(layer.f_node[1]) is torch.nn.SiLU and FUSED_LEVELS and V % 4 == 0:
+            h1 = _PairSiluFn.apply(Ps.contiguous(), Pt.contiguous(), geo)
+        else:
+            h1 = _activation(layer.f_node[1], _PairPreFn.apply(Ps.contiguous(), Pt.contiguous(), geo))
         pre2 = dense(h1, layer.f_node[2].weight, layer.f_node[2].bias)
         if type(layer.f_node[3]) is torch.nn.SiLU and FUSED_LEVELS and V % 4 == 0:
             msg = _SiluMulFn.apply(bw.contiguous(), pre2.contiguous())

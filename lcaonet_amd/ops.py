@@ -956,6 +956,19 @@ def silumul_levels(level: int, a, x, g=None, ha=None, hx=None):
     return _three_level_call("lcao_silumul_levels", level, a, x, (g, ha, hx), lambda t: (t.numel(),))
 
 
+def pairsilu_levels(level: int, Ps, Pt, src_p, dst_p, g=None, hPs=None, hPt=None):
+    """silu(Ps[src] + Pt[dst]) with derivative levels (csrc/lcao_double.hip::k_pairsilu_levels): 0 -> h1; 1 -> dE/dpre;
+    2 -> (d/dg, d/dpre).  The segment sums to the node tables are the caller's."""
+    Ps, Pt = _f32(Ps, "Ps"), _f32(Pt, "Pt")
+    E, V = src_p.numel(), Ps.shape[1]
+    opt = lambda t: _p(_f32(t)) if t is not None else None
+    o0 = torch.empty(E, V, device=Ps.device, dtype=torch.float32)
+    o1 = torch.empty_like(o0) if level == 2 else None
+    _call("lcao_pairsilu_levels", level, _p(Ps), _p(Pt), _p(src_p), _p(dst_p), opt(g), opt(hPs), opt(hPt), E, V, _p(o0),
+          _p(o1) if o1 is not None else None, _stream())
+    return o0 if level < 2 else (o0, o1)
+
+
 ASIDE_WIDTHS = (32, 64, 128)
 
 

@@ -362,13 +362,14 @@ def test_product_primitives_first_and_second_derivatives(dev):
 
 
 def test_fused_level_maps_first_and_second_derivatives(dev):
-    """model/double.py _InjNormFn (F.normalize(a (1 + b))), _SiluMulFn (a silu(x)) and _ASideFn (contraction + gated copy +
+    """model/double.py _InjNormFn (F.normalize(a (1 + b))), _SiluMulFn (a silu(x)), _PairSiluFn (silu(Ps[src] + Pt[dst])) and
+    _ASideFn (contraction + gated copy +
     sum over l + Gram matrix; first level restricted to rb and gate as in the force pass): value, gradient and
     gradient-of-gradient against the same expressions from fp64 tensor ops under autograd."""
     import torch.nn.functional as F
     from lcaonet_amd.data.synthetic import random_periodic_cells
     from lcaonet_amd.model import LCAONet, double
-    from lcaonet_amd.model.double import _ASideFn, _Geo, _InjNormFn, _SiluMulFn
+    from lcaonet_amd.model.double import _ASideFn, _Geo, _InjNormFn, _PairSiluFn, _SiluMulFn
     gen = torch.Generator(device="cpu").manual_seed(11)
     rnd = lambda *shape: torch.randn(*shape, generator=gen).to(dev)
 
@@ -424,6 +425,11 @@ def test_fused_level_maps_first_and_second_derivatives(dev):
         want = chain(literal, dbl([rb, T, gate]), dbl(R), dbl(Hs), first=(0, 2))
         for i, (g_, w_) in enumerate(zip(got, want)):
             assert relerr(g_, w_) <= 1e-5, ("aside", V, i, relerr(g_, w_))
+        Ps, Pt = rnd(geo.N, V), rnd(geo.N, V)
+        R, Hs = [rnd(geo.E, V)], [rnd(geo.N, V), rnd(geo.N, V)]
+        got = chain(lambda x, y: _PairSiluFn.apply(x, y, geo), [Ps, Pt], R, Hs)
+        want = chain(lambda x, y: F.silu(x[geo.src.idx] + y[geo.dst.idx]), dbl([Ps, Pt]), dbl(R), dbl(Hs))
+        assert all(relerr(g_, w_) <= 5e-6 for g_, w_ in zip(got, want)), ("pairsilu", V)
 
 
 def test_rowgram_family_first_and_second_derivatives(dev):
