@@ -1610,3 +1610,216 @@ extern "C" int lcao_pairsilu_levels(int level, const float* Ps, const float* Pt,
   else hipLaunchKernelGGL(k_pairsilu_levels<2>, grid, block, 0, st, Ps, Pt, src_p, dst_p, g, hPs, hPt, n_edges, V / 4, out0, out1);
   return lcao_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same derivative levels as k_aside with the gradient of the species-pair table in the same pass: the edges are
+// visited in the pair-sorted chunk lists of lcao_pair_table_grad (perm, chunk_ptr: <= 64 edges of ONE species pair per
+// chunk), one wave per chunk with its lanes over the channels, so that the pair's table rows stay in registers, every
+// per-edge quantity is lane-local and the chunk's partial table  sum_p (rb[p,d] dX[p,l(d),:] (+ h_rb[p,d] gA[p,l(d),:]))
+// accumulates in registers in list order (dX = gA at level 1, dA at level 2) — gA / dA are never written.  The caller
+// sums each pair's partials in order (lcao_segment_sum): no atomics.  D <= DMAX.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lcao_wave_sum_dpp(float v) {
+  v = lcao_row16_sum(v);
+  const int iv = __float_as_int(v);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), b = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), d = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return (a + b) + (c + d);
+}
+
+template <int R, int NL, int DMAX, int LEVEL>
+__global__ __launch_bounds__(256) void k_aside_pairs(
+    const float* __restrict__ Tf, const float* __restrict__ rb, const int32_t* __restrict__ l_of_d,
+    const int64_t* __restrict__ z, const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p,
+    const float* __restrict__ gate, const float* __restrict__ gAg, const float* __restrict__ gB,
+    const float* __restrict__ gG, const float* __restrict__ h_rb, const float* __restrict__ h_gate,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_ptr, int64_t n_chunks, int D, int V, int zdim,
+    float* __restrict__ o_big0, float* __restrict__ o_row0, float* __restrict__ o_gram, float* __restrict__ o_rb,
+    float* __restrict__ o_row1, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t c = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; c < n_chunks; c += nwave) {
+    const int i0 = chunk_ptr[c], i1 = chunk_ptr[c + 1];
+    float acc[DMAX][R], t[DMAX][R];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+#pragma unroll
+      for (int r = 0; r < R; ++r) { acc[d][r] = 0.f; t[d][r] = 0.f; }
+    if (i0 < i1) {
+      const int pf = perm[i0];
+      const int64_t pair = z[src_p[pf]] * zdim + z[dst_p[pf]];
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d)
+        if (d < D)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int ch = lane + 64 * r;
+            t[d][r] = ch < V ? Tf[(pair * D + d) * V + ch] : 0.f;
+          }
+    }
+    for (int i = i0; i < i1; ++i) {
+      const int64_t p = __builtin_amdgcn_readfirstlane(perm[i]);
+      const int64_t s = __builtin_amdgcn_readfirstlane(src_p[p]);
+      float ge[R], hge[R], gb[R], gag[NL][R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int ch = lane + 64 * r;
+        const bool ok = ch < V;
+        ge[r] = ok ? gate[s * V + ch] : 0.f;
+        hge[r] = (LEVEL == 2 && h_gate && ok) ? h_gate[s * V + ch] : 0.f;
+        gb[r] = ok ? gB[p * V + ch] : 0.f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) gag[l][r] = ok ? gAg[(p * NL + l) * V + ch] : 0.f;
+      }
+      float S[NL][NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int m = 0; m < NL; ++m) S[l][m] = gG[(p * NL + l) * NL + m] + gG[(p * NL + m) * NL + l];
+      float a[NL][R], ah[NL][R];
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < R; ++r) { a[l][r] = 0.f; ah[l][r] = 0.f; }
+      float wv[DMAX], whv[DMAX];
+      int lv[DMAX];
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) {
+        wv[d] = d < D ? rb[p * D + d] : 0.f;
+        whv[d] = (LEVEL == 2 && d < D) ? h_rb[p * D + d] : 0.f;
+        lv[d] = d < D ? l_of_d[d] : -1;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            a[l][r] += (lv[d] == l ? wv[d] : 0.f) * t[d][r];
+            if (LEVEL == 2) ah[l][r] += (lv[d] == l ? whv[d] : 0.f) * t[d][r];
+          }
+      }
+      float gA[NL][R], dX[NL][R];                        // dX: what the table rows are contracted with for d/drb
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float v = gag[l][r] * ge[r] + gb[r];
+#pragma unroll
+          for (int m = 0; m < NL; ++m) v += S[l][m] * a[m][r];
+          gA[l][r] = v;
+          if (LEVEL == 1) dX[l][r] = v;
+        }
+      if (LEVEL == 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          float gp = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) gp += gag[l][r] * a[l][r];
+          if (ch < V) o_row1[p * V + ch] = gp;
+        }
+      } else {
+        float dots[NL][NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+#pragma unroll
+          for (int m = 0; m < NL; ++m) {
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) q += ah[l][r] * a[m][r];
+            dots[l][m] = lcao_wave_sum_dpp(q);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          float dgb = 0.f, dgp = 0.f;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            dgb += ah[l][r];
+            dgp += gag[l][r] * ah[l][r];
+            float da = hge[r] * gag[l][r];
+#pragma unroll
+            for (int m = 0; m < NL; ++m) da += S[m][l] * ah[m][r];
+            dX[l][r] = da;
+            if (ch < V) o_big0[(p * NL + l) * V + ch] = ge[r] * ah[l][r] + hge[r] * a[l][r];
+          }
+          if (ch < V) {
+            o_row0[p * V + ch] = dgb;
+            o_row1[p * V + ch] = dgp;
+          }
+        }
+        if (lane < NL * NL) {
+          const int l = lane / NL, m = lane % NL;
+          float val = 0.f;
+#pragma unroll
+          for (int ll = 0; ll < NL; ++ll)
+#pragma unroll
+            for (int mm = 0; mm < NL; ++mm)
+              if (ll == l && mm == m) val = dots[ll][mm] + dots[mm][ll];
+          o_gram[(p * NL + l) * NL + m] = val;
+        }
+      }
+      float mine = 0.f;                                   // lane d keeps d/drb[d]
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d)
+        if (d < D) {
+          float q = 0.f;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            float sel = 0.f, selg = 0.f;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+              sel = lv[d] == l ? dX[l][r] : sel;
+              selg = lv[d] == l ? gA[l][r] : selg;
+            }
+            q += sel * t[d][r];
+            acc[d][r] += wv[d] * sel + (LEVEL == 2 ? whv[d] * selg : 0.f);
+          }
+          q = lcao_wave_sum_dpp(q);
+          mine = lane == d ? q : mine;
+        }
+      if (lane < D) o_rb[p * D + lane] = mine;
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < D)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int ch = lane + 64 * r;
+          if (ch < V) partial[(c * D + d) * V + ch] = acc[d][r];
+        }
+  }
+}
+
+extern "C" int lcao_aside_pairs(int level, const float* Tf, const float* rb, const int32_t* l_of_d, const int64_t* z,
+                                const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* gAg,
+                                const float* gB, const float* gG, const float* h_rb, const float* h_gate,
+                                const int32_t* perm, const int32_t* chunk_ptr, int64_t n_chunks, int64_t n_edges, int n_orb,
+                                int V, int n_l, int zdim, float* o_big0, float* o_row0, float* o_gram, float* o_rb,
+                                float* o_row1, float* partial, void* stream) {
+  LCAO_CHECK_SIZE(n_edges);
+  LCAO_CHECK_SIZE(n_chunks);
+  if (level < 1 || level > 2 || n_orb <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0 || V <= 0) return LCAO_ERR_INVALID;
+  if (V > 128 || n_orb > 24) return LCAO_ERR_UNSUPPORTED;
+  if (n_chunks == 0) return LCAO_OK;
+  LCAO_CHECK_PTR(Tf); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p);
+  LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(gAg); LCAO_CHECK_PTR(gB); LCAO_CHECK_PTR(gG);
+  LCAO_CHECK_PTR(perm); LCAO_CHECK_PTR(chunk_ptr); LCAO_CHECK_PTR(o_rb); LCAO_CHECK_PTR(o_row1); LCAO_CHECK_PTR(partial);
+  if (level == 2) { LCAO_CHECK_PTR(h_rb); LCAO_CHECK_PTR(o_big0); LCAO_CHECK_PTR(o_row0); LCAO_CHECK_PTR(o_gram); }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(lcao_blocks(n_chunks, 4, 65536)), block(256);
+#define AP_L(R_, NL_, DM_, LV_)                                                                                         \
+  hipLaunchKernelGGL((k_aside_pairs<R_, NL_, DM_, LV_>), grid, block, 0, st, Tf, rb, l_of_d, z, src_p, dst_p, gate, gAg, gB, \
+                     gG, h_rb, h_gate, perm, chunk_ptr, n_chunks, n_orb, V, zdim, o_big0, o_row0, o_gram, o_rb, o_row1, partial)
+#define AP_D(R_, NL_, DM_) { if (level == 1) AP_L(R_, NL_, DM_, 1); else AP_L(R_, NL_, DM_, 2); return lcao_launch_status(); }
+#define AP_NL(R_, NL_)                                                                                                  \
+  if (n_l == NL_) {                                                                                                    \
+    if (n_orb <= 8) AP_D(R_, NL_, 8) else if (n_orb <= 16) AP_D(R_, NL_, 16) else AP_D(R_, NL_, 24)                      \
+  }
+#define AP_R(R_) { AP_NL(R_, 1) AP_NL(R_, 2) AP_NL(R_, 3) AP_NL(R_, 4) }
+  if (V <= 64) AP_R(1) else AP_R(2)
+#undef AP_R
+#undef AP_NL
+#undef AP_D
+#undef AP_L
+  return LCAO_ERR_INVALID;
+}

@@ -328,6 +328,17 @@ def _aside(level, geo, rb, T, gate, **kw):
     return ops.aside_levels(level, T, rb, geo.l_of_d, geo.z, c.src_p, c.dst_p, gate, geo.n_l, geo.zdim, **kw)
 
 
+def _aside_pairs(level, geo, rb, T, gate, gAg, gB, gG, **kw):
+    c = geo.ctx
+    return ops.aside_pairs(level, T, rb, geo.l_of_d, geo.z, c.src_p, c.dst_p, gate, geo.n_l, geo.zdim, geo.perm_pair,
+                           geo.chunk_ptr, gAg, gB, gG, **kw)
+
+
+def _finish_table(geo, partial):
+    n, D, V = partial.shape
+    return ops.segment_sum(partial.reshape(n, D * V), geo.pair_cptr).reshape(-1, D, V)
+
+
 def _aside_from_primitives(geo, rb, T, gate):
     A = _ContractFn.apply(rb, T, geo)
     Ag, B = _GateSumFn.apply(A.contiguous(), gather(gate, geo.src))
@@ -355,6 +366,9 @@ class _ASideFn(Function):
             g_rb, g_gate = _ASideBwdFn.apply(gAg, gB, gG, rb, T, gate, geo)
             return g_rb, None, g_gate, None
         if not torch.is_grad_enabled():                     # a plain backward: the fused level with the table gradient
+            if rb.shape[1] <= ops.ASIDE_PAIRS_MAX_ORB:
+                g_rb, part, partial = _aside_pairs(1, geo, rb, T, gate, gAg, gB, gG)
+                return g_rb, _finish_table(geo, partial), ops.segment_sum(part, geo.src.ptr), None
             g_rb, part, gA = _aside(1, geo, rb, T, gate, gAg=gAg, gB=gB, gG=gG, want_table_terms=True)
             return g_rb, _c3(geo, gA, rb, V), ops.segment_sum(part, geo.src.ptr), None
         # every gradient, with a graph: the primitives (each closed under differentiation) on the saved inputs
@@ -385,6 +399,9 @@ class _ASideBwdFn(Function):
         h_rb = torch.zeros_like(rb) if h_rb is None else h_rb.contiguous()
         h_gate = None if h_gate is None else h_gate.contiguous()
         with_T = ctx.needs_input_grad[4]
+        if with_T and rb.shape[1] <= ops.ASIDE_PAIRS_MAX_ORB:
+            out = _aside_pairs(2, geo, rb, T, gate, gAg, gB, gG, h_rb=h_rb, h_gate=h_gate)
+            return (out[0], out[1], out[2], out[3], _finish_table(geo, out[5]), ops.segment_sum(out[4], geo.src.ptr), None)
         out = _aside(2, geo, rb, T, gate, gAg=gAg, gB=gB, gG=gG, h_rb=h_rb, h_gate=h_gate, want_table_terms=with_T)
         d_T = None
         if with_T:
