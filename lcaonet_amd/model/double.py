@@ -108,9 +108,13 @@ def wgrad(g: Tensor, x: Tensor) -> Tensor:
 class IndexPlan:
     """An index vector (n_out rows picking from n_rows table rows) with the sorted-segment structure of its adjoint."""
 
-    def __init__(self, idx: Tensor, n_rows: int, is_sorted: bool = False):
+    def __init__(self, idx: Tensor, n_rows: int, is_sorted: bool = False, lists=None):
+        """lists = (perm, ptr): the stable argsort of idx and its segment bounds when the caller already has them."""
         self.idx = idx.to(torch.int64).contiguous()
         self.n_rows = n_rows
+        if lists is not None:
+            self.perm, self.ptr = lists[0].to(torch.int32), lists[1].to(torch.int32)
+            return
         if is_sorted:
             perm = torch.arange(idx.numel(), device=idx.device)
             srt = self.idx
@@ -180,10 +184,15 @@ class _Geo:
         self.l_of_d, self.n_l = model.shbf.l_of_d, model.n_l
         self.zdim = model.emb_layer.max_z + 1
         order = ctx.order.long()
-        self.src, self.dst = IndexPlan(ctx.src_p, self.N, is_sorted=True), IndexPlan(ctx.dst_p, self.N)
+        # in-edge lists of the CSR build = the stable argsort of dst_p (in_pos: p-indices grouped by target, ascending)
+        self.src = IndexPlan(ctx.src_p, self.N, is_sorted=True)
+        self.dst = IndexPlan(ctx.dst_p, self.N, lists=(ctx.in_pos, ctx.in_ptr))
         # the owned out-edges: gathers from (N, .) node tables, scatter into the n_own centre rows
-        self.src_o = IndexPlan(ctx.src_p[: self.e_own], self.N, is_sorted=True)
-        self.dst_o = IndexPlan(ctx.dst_p[: self.e_own], self.N)
+        if self.e_own == self.E:
+            self.src_o, self.dst_o = self.src, self.dst
+        else:
+            self.src_o = IndexPlan(ctx.src_p[: self.e_own], self.N, is_sorted=True)
+            self.dst_o = IndexPlan(ctx.dst_p[: self.e_own], self.N)
         self.agg = IndexPlan(ctx.src_p[: self.e_own], self.n_own, is_sorted=True)
         self.zplan = IndexPlan(z, self.zdim)
         batch = graph.get(GraphKeys.Batch_idx)
@@ -759,6 +768,11 @@ class _TripletWeightBwdFn(Function):
         return ggw, gc2, gG2, None
 
 
+def _head(t: Tensor, n: int) -> Tensor:
+    """t[:n] — the tensor itself when that is all of it (a slice node costs a zero fill and a copy per backward pass)."""
+    return t if t.shape[0] == n else t[:n]
+
+
 def _triplet_weights(geo: _Geo, u: Tensor, G: Tensor) -> Tensor:
     """w[t, l] = Y_l(u_p . u_q) / max(sqrt(Y^T G_q Y), 1e-12), zero for q == p  (lcaonet.py:179-184 in Gram form).
     The cosines are an sddmm of the (zero-padded) unit vectors with themselves — the bilinear family again — and the
@@ -766,7 +780,7 @@ def _triplet_weights(geo: _Geo, u: Tensor, G: Tensor) -> Tensor:
     through an elementwise torch op."""
     u4 = F.pad(u, (0, 1))
     # out-edge side: the e_own owned-centre edges; in-edge side: every local edge (the same split as tbw = spmm(w, Ag))
-    c = _SddmmFn.apply(u4[: geo.e_own], u4.unsqueeze(1), geo).squeeze(1)       # (T,)
+    c = _SddmmFn.apply(_head(u4, geo.e_own), u4.unsqueeze(1), geo).squeeze(1)   # (T,)
     return _TripletWeightFn.apply(c, G, geo)
 
 
@@ -821,14 +835,14 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
             G = _GramFn.apply(A.contiguous())
         tbw = _SpmmFn.apply(_triplet_weights(geo, u, G), Ag, geo)               # (e_own, V)
         ft = dense(tbw, layer.f_three[0].weight)
-        B = B[: geo.e_own]
+        B = _head(B, geo.e_own)
         if Bv is None and FUSED_LEVELS:
             lw = _InjNormFn.apply(B.contiguous(), ft.contiguous())            # F.normalize(B (1 + ft), dim=-1)
         else:
             if Bv is None:
                 lw_in = mulp(B, ft, 1.0)
             else:
-                Bv = Bv[: geo.e_own]
+                Bv = _head(Bv, geo.e_own)
                 lw_in = (B + B * ft[:, :V]) + (Bv + Bv * ft[:, V:])
             lw = _RowNormFn.apply(lw_in.contiguous())
         bw = dense(lw, layer.basis_weight.weight)
@@ -841,7 +855,7 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
             msg = _SiluMulFn.apply(bw.contiguous(), pre2.contiguous())
         else:
             msg = mulp(bw, _activation(layer.f_node[3], pre2), 0.0)
-        x = x[:n_own] + dense(scatter_sum(msg, geo.agg), layer.out_weight.weight)
+        x = _head(x, n_own) + dense(scatter_sum(msg, geo.agg), layer.out_weight.weight)
     prop = _mlp(model.out_layer.out_lin, x)
     batch = graph.get(GraphKeys.Batch_idx)
     ext = model.out_layer.is_extensive
