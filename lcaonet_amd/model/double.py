@@ -884,16 +884,103 @@ def energy(model, graph, pos: Tensor, x_tab: Tensor, cst_pair: Tensor, with_dire
     return out, scatter_sum(f, geo.agg)
 
 
+def _graph_groups(graph, n_groups: int):
+    """Split a batch of independent graphs into n_groups runs of consecutive graphs: [(sub-batch, node range, graph range)].
+    Nodes of a graph are consecutive (batch index sorted, as every collate produces it); edges may come in any order.
+    One small device-to-host copy (the node and edge bounds of the groups)."""
+    from ..data.graph import Data
+    from .base import num_graphs
+    from .lcaonet import EdgeContext
+
+    batch = graph[GraphKeys.Batch_idx]
+    B = num_graphs(graph, batch)
+    n_groups = max(1, min(n_groups, B))
+    g_bounds = [(B * k) // n_groups for k in range(n_groups + 1)]
+    N = batch.numel()
+    ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], N)
+    n_ptr = torch.searchsorted(batch.contiguous(), torch.tensor(g_bounds, device=batch.device, dtype=batch.dtype))
+    e_ptr = ctx.out_ptr.long()[n_ptr]                              # p-space is sorted by centre: a node range is an edge range
+    n_b, e_b = torch.stack([n_ptr, e_ptr]).tolist()
+    if any(int(batch[n_b[k]: n_b[k + 1]].numel()) == 0 for k in range(n_groups)):
+        raise ValueError("force_training_chunks: a group of graphs has no atoms")
+    order = ctx.order.long()
+    idx = graph[GraphKeys.Edge_idx]
+    groups = []
+    for k in range(n_groups):
+        n0, n1, e0, e1, b0, b1 = n_b[k], n_b[k + 1], e_b[k], e_b[k + 1], g_bounds[k], g_bounds[k + 1]
+        ids = order[e0:e1]
+        sub = Data(**{GraphKeys.Z: graph[GraphKeys.Z][n0:n1], GraphKeys.Pos: graph[GraphKeys.Pos][n0:n1],
+                      GraphKeys.Edge_idx: (idx[:, ids] - n0).contiguous(), GraphKeys.Batch_idx: batch[n0:n1] - b0})
+        if graph.get(GraphKeys.Edge_shift) is not None:
+            sub[GraphKeys.Edge_shift] = graph[GraphKeys.Edge_shift][ids]
+            sub[GraphKeys.Lattice] = graph[GraphKeys.Lattice].reshape(-1, 3, 3)[b0:b1]
+        sub["num_graphs"] = b1 - b0
+        groups.append((sub, (n0, n1), (b0, b1)))
+    return groups
+
+
+class _RecomputedForcesFn(Function):
+    """(out, force) of forward_exact_forces with a bounded footprint: the forward pass is the fused graph-less sweep
+    (model/forces.py); the backward pass rebuilds the twice-differentiable graph for one group of graphs at a time —
+    graphs of a batch do not interact — applies the cotangents of (out, force) and frees it before the next group.  The same
+    derivative (no step size), the forward work of the fused sweep added, the peak memory of ONE group's graph."""
+
+    @staticmethod
+    def forward(ctx, handle, x_tab, cst_pair, *params):
+        from .forces import forward_with_autograd_forces
+
+        model, graph, n_groups = handle
+        ctx.handle = handle
+        ctx.save_for_backward(x_tab, cst_pair)
+        zdim = model.emb_layer.max_z + 1
+        return forward_with_autograd_forces(model, graph, tables=(x_tab.detach().contiguous(), cst_pair.detach().contiguous(), zdim))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_force):
+        model, graph, n_groups = ctx.handle
+        x_tab, cst_pair = ctx.saved_tensors
+        params = [p for p in model.parameters() if p.requires_grad]
+        xt, cp = x_tab.detach().requires_grad_(True), cst_pair.detach().requires_grad_(True)
+        wrt = [xt, cp] + params
+        total = [None] * len(wrt)
+        for sub, (n0, n1), (b0, b1) in _graph_groups(graph, n_groups):
+            with torch.enable_grad():
+                pos = sub[GraphKeys.Pos].detach().float().requires_grad_(True)
+                out = energy(model, sub, pos, xt, cp)
+                s = (out * g_out[b0:b1]).sum() if g_out is not None else 0.0
+                if g_force is not None:
+                    with positions_only():
+                        for i in range(model.out_size):
+                            f_i = -torch.autograd.grad(out[:, i].sum(), pos, create_graph=True)[0]
+                            gf = g_force[n0:n1] if model.out_size == 1 else g_force[n0:n1, i]
+                            s = s + (f_i * gf).sum()
+                grads = torch.autograd.grad(s, wrt, allow_unused=True)
+            for j, g in enumerate(grads):
+                if g is not None:
+                    total[j] = g if total[j] is None else total[j] + g
+            del out, s, grads, pos
+        return (None, total[0], total[1], *total[2:])
+
+
 def forward_exact_forces(model, graph, update_stats: bool = True, tables=None):
     """(out, force): LCAONet.forward for regress_forces=True, direct_forces=False with BOTH results carrying an autograd
     graph to every parameter — `force` through the exact second derivative.  Train or eval mode (BatchNorm statistics as
-    in model/train.py)."""
+    in model/train.py).  model.force_training_chunks = k > 1 (batched graphs, SiLU, built-in basis): the graph is not
+    kept but rebuilt in the backward pass for k groups of graphs in turn (_RecomputedForcesFn)."""
     from .train import species_tables_autograd
 
     z = model.checked_z(graph)
     idx_s, idx_t = graph[GraphKeys.Edge_idx]
     ops._dev(graph[GraphKeys.Pos], "graph.pos")
     x_tab, cst_pair = tables if tables is not None else species_tables_autograd(model, z, idx_s, idx_t, update_stats)[:2]
+    n_groups = int(getattr(model, "force_training_chunks", 1) or 1)
+    if n_groups > 1 and graph.get(GraphKeys.Batch_idx) is not None:
+        from .forces import _check_supported
+
+        _check_supported(model, have_tables=True)           # raises NotImplementedError with the reason
+        params = [p for p in model.parameters() if p.requires_grad]
+        return _RecomputedForcesFn.apply((model, graph, n_groups), x_tab, cst_pair, *params)
     with torch.enable_grad():
         pos = graph[GraphKeys.Pos].detach().float().requires_grad_(True)
         out = energy(model, graph, pos, x_tab, cst_pair)

@@ -102,6 +102,43 @@ def test_fused_levels_equal_their_composition_from_primitives(dev, V, n_int, tra
         assert worst <= 2e-5, worst
 
 
+@pytest.mark.parametrize("training,chunks", [(True, 2), (False, 3), (True, 7)])
+def test_force_training_in_groups_of_graphs_gives_the_same_gradients(dev, training, chunks):
+    """model.force_training_chunks = k: forward by the fused graph-less sweep, the twice-differentiable graph rebuilt in the
+    backward pass for k groups of graphs in turn (double._RecomputedForcesFn) — energy, forces, every parameter gradient
+    and the BatchNorm statistics equal those of the one-graph path; edges of the batch in shuffled order."""
+    from lcaonet_amd.data.synthetic import random_periodic_cells
+    kw = dict(emb_size=32, emb_size_coeff=32, emb_size_conv=64, n_interaction=2, cutoff=5.0, regress_forces=True,
+              direct_forces=False)
+    m, _ = _random_model(dev, 99, grad=True, **kw)
+    m.train(training)
+    g = random_periodic_cells(5, 8, 6.0, 0.99 * 5.0, seed=5).to(dev)
+    perm = torch.randperm(g["edge_index"].shape[1], generator=torch.Generator().manual_seed(3)).to(dev)
+    g["edge_index"], g["edge_shift"] = g["edge_index"][:, perm].contiguous(), g["edge_shift"][perm].contiguous()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def run(k):
+        m.load_state_dict(state)
+        m.force_training_chunks = k
+        m.zero_grad(set_to_none=True)
+        e, f = m(g)
+        assert e.requires_grad and f.requires_grad
+        (0.1 * (e ** 2).mean() + ((f - 0.05) ** 2).mean()).backward()
+        stats = {n: b.clone() for n, b in m.named_buffers() if "running" in n}
+        return e.detach(), f.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, stats
+
+    try:
+        e0, f0, g0, s0 = run(1)
+        e1, f1, g1, s1 = run(chunks)
+    finally:
+        m.force_training_chunks = 1
+    assert relerr(e1, e0) <= 5e-6 and relerr(f1, f0) <= 2e-5
+    assert g1.keys() == g0.keys() and len(g1) > 25
+    worst = max(relerr(g1[n], g0[n]) for n in g0 if float(g0[n].abs().max()) > 1e-12)
+    assert worst <= 2e-5, worst
+    assert all(torch.equal(s0[n], s1[n]) for n in s0)
+
+
 def test_eval_mode_forces_are_differentiable_and_match_the_inference_sweep(dev):
     """Eval mode with autograd on returns forces WITH a graph (the reference's create_graph=True), equal to the fast
     graph-less inference sweep (frozen parameters / torch.no_grad()); the force graph reaches pos-independent parameters

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--torch-profile", action="store_true")
     ap.add_argument("--mode", default="forces", choices=["forces", "energy", "infer-forces"],
                     help="forces: train on energy + autograd forces; energy: train on energy only; infer-forces: eval, no grad")
+    ap.add_argument("--chunks", type=int, default=1, help="model.force_training_chunks")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -37,6 +38,7 @@ def main():
     forces = args.mode != "energy"
     m = bench.build_model(dict(model_kw, regress_forces=forces, direct_forces=False) if forces else model_kw, 1234, dev)
     m = m.eval() if args.mode == "infer-forces" else m.train()
+    m.force_training_chunks = args.chunks
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     e_t = torch.zeros(args.n_cells, 1, device=dev)
     f_t = torch.zeros(N, 3, device=dev)
