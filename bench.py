@@ -441,6 +441,10 @@ def main():
         "lcao_triplet_bwd_mfma": ("hbm", 8.0 * NL_ * V_ + 4.0 * V_ + 116.0, PEAK_HBM_GBS, "GB/s",
                                   "in- and out-edge lists are cut into 16-wide MFMA tiles (a degree-18 list fills them to 32 %): "
                                   "the kernel sits between its HBM and matrix ceilings (DESIGN.md section 4)"),
+        # force training: levels 1 and 2 of the contraction + pair-table gradient, launched equally often (mean of the two)
+        "lcao_aside_pairs": ("hbm", 0.5 * ((4.0 * V_ * (NL_ + 3) + 8.0 * D_ + 4.0 * NL_ * NL_) * 2 + 4.0 * V_ * 1 + 4.0 * D_
+                                           + 4.0 * V_ * (NL_ + 2) + 4.0 * D_ + 4.0 * NL_ * NL_ + 4.0 * V_), PEAK_HBM_GBS, "GB/s",
+                             "mean over its two derivative levels (gAg, gB, gate rows read; level 2 also writes d/dgAg)"),
         "lcao_pair_contract_bwd": ("hbm", 4.0 * NL_ * V_ + 8.0 * V_ + 40.0 + 8.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
         "lcao_pair_contract": ("hbm", 4.0 * (NL_ + 1) * V_ + 40.0 + 4.0 * D_, PEAK_HBM_GBS, "GB/s", ""),
         "lcao_triplet_gemm": ("hbm", 4.0 * NL_ * V_ + 52.0 + 4.0 * V_, PEAK_HBM_GBS, "GB/s", ""),
@@ -519,6 +523,18 @@ def main():
                 ftrain_ms = 1e3 * (time.perf_counter() - t1) / 2
                 roof_ftrain = mode_roofline(force_train_step, 1, mode_work, E)
                 ftrain_peak_gib = torch.cuda.max_memory_allocated() / 2**30
+                # the same step with the graph rebuilt in the backward pass for two groups of crystals in turn
+                fopt.zero_grad(set_to_none=True)
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats()
+                ftm.force_training_chunks = 2
+                force_train_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    force_train_step()
+                torch.cuda.synchronize()
+                ftrain2 = (1e3 * (time.perf_counter() - t1) / 2, torch.cuda.max_memory_allocated() / 2**30)
                 del ftm, fopt
                 torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
@@ -648,7 +664,11 @@ def main():
                         "(create_graph), L1 loss on both, backward through the force graph (twice-differentiable HIP "
                         "primitives, model/double.py) + Adam step",
                 "ms_per_step_rank0": round(ftrain_ms, 3), "edges_per_s_rank0": E / (ftrain_ms * 1e-3),
-                "peak_memory_GiB": round(ftrain_peak_gib, 1), "roofline": roof_ftrain}
+                "peak_memory_GiB": round(ftrain_peak_gib, 1), "roofline": roof_ftrain,
+                "in_two_groups_of_graphs": {
+                    "note": "model.force_training_chunks = 2: forward by the fused graph-less sweep, the twice-differentiable "
+                            "graph rebuilt in the backward pass for one half of the crystals at a time (same gradients)",
+                    "ms_per_step_rank0": round(ftrain2[0], 3), "peak_memory_GiB": round(ftrain2[1], 1)}}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
