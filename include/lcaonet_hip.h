@@ -461,12 +461,17 @@ int lcao_aside_levels(int level, const float* Tf, const float* rb, const int32_t
  * pair-sorted chunk lists of lcao_pair_table_grad (perm, chunk_ptr), the per-edge outputs are those of lcao_aside_levels
  * (written at the edges' own rows) and `partial` (n_chunks, D, V) receives each chunk's part of
  *   level 1: dE/dTf = sum_p rb[p,d] gA[p,l(d),:]        level 2: d/dTf = sum_p (h_rb[p,d] gA[p,l(d),:] + rb[p,d] dA[p,l(d),:])
- * (lcao_segment_sum over the pair's chunks finishes it) — gA and dA are never written.  V <= 128, n_orb <= 24. */
+ * (lcao_segment_sum over the pair's chunks finishes it) — gA and dA are never written.  V <= 128, n_orb <= 24.
+ * order (nullable): rb, h_rb and o_rb rows are in the caller's edge order, order[p] = that row of p-space edge p (as in
+ * lcao_pair_contract_bwd).  gram_tri = 1 (level 1 only): gG is the (E, 10) upper triangle in Gram coordinates that
+ * lcao_triplet_bwd* writes — the first-order training sweep (model/train.py) calls this instead of
+ * lcao_pair_contract_bwd + lcao_pair_table_grad. */
 int lcao_aside_pairs(int level, const float* Tf, const float* rb, const int32_t* l_of_d, const int64_t* z,
                      const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* gAg, const float* gB,
                      const float* gG, const float* h_rb, const float* h_gate, const int32_t* perm, const int32_t* chunk_ptr,
-                     int64_t n_chunks, int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* o_big0, float* o_row0,
-                     float* o_gram, float* o_rb, float* o_row1, float* partial, void* stream);
+                     const int32_t* order, int gram_tri, int64_t n_chunks, int64_t n_edges, int n_orb, int V, int n_l,
+                     int zdim, float* o_big0, float* o_row0, float* o_gram, float* o_rb, float* o_row1, float* partial,
+                     void* stream);
 
 /* Two fused maps of the edge chain with the same derivative levels (the tensor between the two fused steps is never
  * stored): injnorm y = x / max(|x|, eps) per row with x = a (1 + b)  (lcaonet.py:192-196: a = B, b = ft) and

@@ -89,7 +89,7 @@ SIGNATURES = {
     "lcao_injnorm_levels": [I, P, P, P, P, P, L, I, F, P, P, P, P],
     "lcao_silumul_levels": [I, P, P, P, P, P, L, P, P, P, P],
     "lcao_pairsilu_levels": [I, P, P, P, P, P, P, P, L, I, P, P, P],
-    "lcao_aside_pairs": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, P, P, P, P, P, P, P],
+    "lcao_aside_pairs": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, L, L, I, I, I, I, P, P, P, P, P, P, P],
     "lcao_bcast_fma": [P, P, P, P, P, L, I, I, P, P],
     "lcao_lsum_mul": [P, P, L, I, I, P, P],
     "lcao_silu_levels": [I, P, P, P, L, P, P, P],

@@ -1633,9 +1633,9 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
     const int64_t* __restrict__ z, const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p,
     const float* __restrict__ gate, const float* __restrict__ gAg, const float* __restrict__ gB,
     const float* __restrict__ gG, const float* __restrict__ h_rb, const float* __restrict__ h_gate,
-    const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_ptr, int64_t n_chunks, int D, int V, int zdim,
-    float* __restrict__ o_big0, float* __restrict__ o_row0, float* __restrict__ o_gram, float* __restrict__ o_rb,
-    float* __restrict__ o_row1, float* __restrict__ partial) {
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ order,
+    int gram_tri, int64_t n_chunks, int D, int V, int zdim, float* __restrict__ o_big0, float* __restrict__ o_row0,
+    float* __restrict__ o_gram, float* __restrict__ o_rb, float* __restrict__ o_row1, float* __restrict__ partial) {
   const int lane = threadIdx.x & 63;
   const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t c = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; c < n_chunks; c += nwave) {
@@ -1660,6 +1660,7 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
     for (int i = i0; i < i1; ++i) {
       const int64_t p = __builtin_amdgcn_readfirstlane(perm[i]);
       const int64_t s = __builtin_amdgcn_readfirstlane(src_p[p]);
+      const int64_t e = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[p]) : p;   // row of rb / d/drb (caller's order)
       float ge[R], hge[R], gb[R], gag[NL][R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -1675,7 +1676,14 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
 #pragma unroll
       for (int l = 0; l < NL; ++l)
 #pragma unroll
-        for (int m = 0; m < NL; ++m) S[l][m] = gG[(p * NL + l) * NL + m] + gG[(p * NL + m) * NL + l];
+        for (int m = 0; m < NL; ++m) {
+          if (gram_tri) {                                  // (E, 10) upper triangle of a 4 x 4 block, Gram coordinates
+            const int lo = l < m ? l : m, hi = l < m ? m : l;
+            S[l][m] = gG[p * 10 + lcao_tri_idx(lo, hi)] * (l == m ? 2.0f : 1.0f);
+          } else {
+            S[l][m] = gG[(p * NL + l) * NL + m] + gG[(p * NL + m) * NL + l];
+          }
+        }
       float a[NL][R], ah[NL][R];
 #pragma unroll
       for (int l = 0; l < NL; ++l)
@@ -1685,8 +1693,8 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
       int lv[DMAX];
 #pragma unroll
       for (int d = 0; d < DMAX; ++d) {
-        wv[d] = d < D ? rb[p * D + d] : 0.f;
-        whv[d] = (LEVEL == 2 && d < D) ? h_rb[p * D + d] : 0.f;
+        wv[d] = d < D ? rb[e * D + d] : 0.f;
+        whv[d] = (LEVEL == 2 && d < D) ? h_rb[e * D + d] : 0.f;
         lv[d] = d < D ? l_of_d[d] : -1;
 #pragma unroll
         for (int l = 0; l < NL; ++l)
@@ -1777,7 +1785,7 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
           q = lcao_wave_sum_dpp(q);
           mine = lane == d ? q : mine;
         }
-      if (lane < D) o_rb[p * D + lane] = mine;
+      if (lane < D) o_rb[e * D + lane] = mine;
     }
 #pragma unroll
     for (int d = 0; d < DMAX; ++d)
@@ -1793,12 +1801,13 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
 extern "C" int lcao_aside_pairs(int level, const float* Tf, const float* rb, const int32_t* l_of_d, const int64_t* z,
                                 const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* gAg,
                                 const float* gB, const float* gG, const float* h_rb, const float* h_gate,
-                                const int32_t* perm, const int32_t* chunk_ptr, int64_t n_chunks, int64_t n_edges, int n_orb,
-                                int V, int n_l, int zdim, float* o_big0, float* o_row0, float* o_gram, float* o_rb,
-                                float* o_row1, float* partial, void* stream) {
+                                const int32_t* perm, const int32_t* chunk_ptr, const int32_t* order, int gram_tri,
+                                int64_t n_chunks, int64_t n_edges, int n_orb, int V, int n_l, int zdim, float* o_big0,
+                                float* o_row0, float* o_gram, float* o_rb, float* o_row1, float* partial, void* stream) {
   LCAO_CHECK_SIZE(n_edges);
   LCAO_CHECK_SIZE(n_chunks);
   if (level < 1 || level > 2 || n_orb <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0 || V <= 0) return LCAO_ERR_INVALID;
+  if (gram_tri && level != 1) return LCAO_ERR_INVALID;
   if (V > 128 || n_orb > 24) return LCAO_ERR_UNSUPPORTED;
   if (n_chunks == 0) return LCAO_OK;
   LCAO_CHECK_PTR(Tf); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p);
@@ -1809,7 +1818,8 @@ extern "C" int lcao_aside_pairs(int level, const float* Tf, const float* rb, con
   dim3 grid(lcao_blocks(n_chunks, 4, 65536)), block(256);
 #define AP_L(R_, NL_, DM_, LV_)                                                                                         \
   hipLaunchKernelGGL((k_aside_pairs<R_, NL_, DM_, LV_>), grid, block, 0, st, Tf, rb, l_of_d, z, src_p, dst_p, gate, gAg, gB, \
-                     gG, h_rb, h_gate, perm, chunk_ptr, n_chunks, n_orb, V, zdim, o_big0, o_row0, o_gram, o_rb, o_row1, partial)
+                     gG, h_rb, h_gate, perm, chunk_ptr, order, gram_tri, n_chunks, n_orb, V, zdim, o_big0, o_row0, o_gram, o_rb, \
+                     o_row1, partial)
 #define AP_D(R_, NL_, DM_) { if (level == 1) AP_L(R_, NL_, DM_, 1); else AP_L(R_, NL_, DM_, 2); return lcao_launch_status(); }
 #define AP_NL(R_, NL_)                                                                                                  \
   if (n_l == NL_) {                                                                                                    \

@@ -266,12 +266,20 @@ class LCAOStackFn(torch.autograd.Function):
                 return ops.segment_sum(partial.reshape(partial.shape[0], D * V), geom.pair_cptr).reshape(-1, D, V)
 
             Te = sv["Tf"][0] if valence else sv["Tf"]
-            g_gate_part, g_A = ops.pair_contract_bwd(Te, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"],
-                                                     g_Ag, torch.zeros_like(g_B) if valence else g_B, g_gram, E, geom.n_l,
-                                                     geom.zd, g_rb_sink, want_gA=True)
+            if not valence and V <= 128 and D <= ops.ASIDE_PAIRS_MAX_ORB:
+                # contraction backward and the table gradient in ONE pass over the pair-sorted chunks (dE/dA never written)
+                _, g_gate_part, partial = ops.aside_pairs(1, Te, rb, geom.l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"], geom.n_l,
+                                                          geom.zd, geom.perm_pair, geom.chunk_ptr, g_Ag, g_B, g_gram,
+                                                          order=ctx.order, gram_tri=True)
+                g_Tf[i] = ops.segment_sum(partial.reshape(partial.shape[0], D * V), geom.pair_cptr).reshape(-1, D, V)
+                g_A = None
+            else:
+                g_gate_part, g_A = ops.pair_contract_bwd(Te, rb, ctx.order, geom.l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"],
+                                                         g_Ag, torch.zeros_like(g_B) if valence else g_B, g_gram, E, geom.n_l,
+                                                         geom.zd, g_rb_sink, want_gA=True)
             if valence:   # A sees Tc + Tv, B sees Tc, Bv sees Tv: the shared part of g_A plus each half's own g_B
                 g_Tf[i] = torch.cat([table_grad(g_A + g_B.unsqueeze(1)), table_grad(g_A + g_Bv.unsqueeze(1))], dim=-1)
-            else:
+            elif g_A is not None:
                 g_Tf[i] = table_grad(g_A)
             g_gate = ops.segment_sum(g_gate_part, ctx.out_ptr)
             g_xk = ops.act_bwd(g_gate, sv["xk"], ops.ACT_SIGMOID)

@@ -1014,15 +1014,16 @@ ASIDE_PAIRS_MAX_ORB = 24
 
 
 def aside_pairs(level: int, Tf, rb, l_of_d, z, src_p, dst_p, gate, n_l: int, zdim: int, perm, chunk_ptr, gAg, gB, gG,
-                h_rb=None, h_gate=None):
+                h_rb=None, h_gate=None, order=None, gram_tri: bool = False):
     """Levels 1 / 2 of aside_levels with the per-chunk parts of the table gradient (csrc/lcao_double.hip::k_aside_pairs):
     1 -> (g_rb, g_gate_part, partial);  2 -> (d_gAg, d_gB, d_gG, d_rb, d_gate_part, partial);  partial (n_chunks, D, V)."""
     Tf, rb, gate = _f32(Tf, "Tf"), _f32(rb, "rb"), _f32(gate, "gate")
     gAg, gB, gG = _f32(gAg, "gAg"), _f32(gB, "gB"), _f32(gG, "gG")
     E, D = rb.shape
     V = Tf.shape[-1]
-    if gAg.shape != (E, n_l, V) or gB.shape != (E, V) or gG.shape != (E, n_l, n_l) or Tf.shape[:2] != (zdim * zdim, D):
-        raise ValueError("aside_pairs: gAg (E, n_l, V), gB (E, V), gG (E, n_l, n_l), Tf (zdim^2, D, V)")
+    if (gAg.shape != (E, n_l, V) or gB.shape != (E, V) or gG.shape != ((E, 10) if gram_tri else (E, n_l, n_l))
+            or Tf.shape[:2] != (zdim * zdim, D)):
+        raise ValueError("aside_pairs: gAg (E, n_l, V), gB (E, V), gG (E, n_l, n_l) or (E, 10), Tf (zdim^2, D, V)")
     dev = rb.device
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
     opt = lambda t: _p(t) if t is not None else None
@@ -1035,7 +1036,8 @@ def aside_pairs(level: int, Tf, rb, l_of_d, z, src_p, dst_p, gate, n_l: int, zdi
     gram = new(E, n_l, n_l) if level == 2 else None
     o_rb, row1, partial = new(E, D), new(E, V), new(n_chunks, D, V)
     _call("lcao_aside_pairs", level, _p(Tf), _p(rb), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate), _p(gAg), _p(gB),
-          _p(gG), opt(h_rb), opt(h_gate), _p(perm), _p(chunk_ptr), n_chunks, E, D, V, n_l, zdim, opt(big0), opt(row0),
+          _p(gG), opt(h_rb), opt(h_gate), _p(perm), _p(chunk_ptr), opt(order), int(gram_tri), n_chunks, E, D, V, n_l, zdim,
+          opt(big0), opt(row0),
           opt(gram), _p(o_rb), _p(row1), _p(partial), _stream())
     return (o_rb, row1, partial) if level == 1 else (big0, row0, gram, o_rb, row1, partial)
 

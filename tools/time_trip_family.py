@@ -52,9 +52,33 @@ def main():
         ("spmm_t cos", lambda: ops.trip_spmm_t(w1, u4[:, 0], geo), 4 * (T + 8 * E)),
         ("sddmm  cos", lambda: ops.trip_sddmm(u4[:, 0], u4, geo), 4 * (T + 8 * E)),
     ]
+    c = geo.ctx
+    D = len(geo.l_of_d)
+    rb, Tt, gate = rnd(E, D), rnd(geo.zdim ** 2, D, V), rnd(geo.N, V)
+    gAg, gB, gG, h_rb, h_gate = rnd(E, L, V), rnd(E, V), rnd(E, L, L), rnd(E, D), rnd(geo.N, V)
+    asl = lambda lv, **kw: ops.aside_levels(lv, Tt, rb, geo.l_of_d, geo.z, c.src_p, c.dst_p, gate, L, geo.zdim, **kw)
+    asp = lambda lv, **kw: ops.aside_pairs(lv, Tt, rb, geo.l_of_d, geo.z, c.src_p, c.dst_p, gate, L, geo.zdim, geo.perm_pair,
+                                           geo.chunk_ptr, gAg, gB, gG, **kw)
+    g10, g_rb = rnd(E, 10), torch.zeros(E, D, device=dev)
+    row = 4 * V
+    rows += [
+        ("aside level 0", lambda: asl(0), E * (row * (L + 1) + 4 * D + 4 * L * L)),
+        ("aside level 1", lambda: asl(1, gAg=gAg, gB=gB, gG=gG), E * (row * (L + 3) + 8 * D)),
+        ("aside level 1 + gA", lambda: asl(1, gAg=gAg, gB=gB, gG=gG, want_table_terms=True), E * (row * (2 * L + 3) + 8 * D)),
+        ("aside level 2 + gA, dA", lambda: asl(2, gAg=gAg, gB=gB, gG=gG, h_rb=h_rb, h_gate=h_gate, want_table_terms=True),
+         E * (row * (4 * L + 6) + 12 * D)),
+        ("aside_pairs level 1 (+ table)", lambda: asp(1), E * (row * (L + 3) + 8 * D)),
+        ("aside_pairs level 2 (+ table)", lambda: asp(2, h_rb=h_rb, h_gate=h_gate), E * (row * (2 * L + 6) + 12 * D)),
+        ("pair_contract_bwd (forces)", lambda: ops.pair_contract_bwd(Tt, rb, None, geo.l_of_d, geo.z, c.src_p, c.dst_p, gate, gAg,
+                                                                      gB, g10, E, L, geo.zdim, g_rb), E * (row * (L + 3) + 8 * D)),
+        ("pair_contract_bwd + gA (training)", lambda: ops.pair_contract_bwd(Tt, rb, None, geo.l_of_d, geo.z, c.src_p, c.dst_p,
+                                                                             gate, gAg, gB, g10, E, L, geo.zdim, g_rb, want_gA=True),
+         E * (row * (2 * L + 3) + 8 * D)),
+        ("pair_table_grad", lambda: ops.pair_table_grad(gAg, rb, None, geo.l_of_d, geo.perm_pair, geo.chunk_ptr), E * (row * L + 4 * D)),
+    ]
     for name, fn, nbytes in rows:
         ms = timed(fn, args.iters)
-        print(f"{name:28s} {ms:8.3f} ms   {gb(nbytes, ms):8.0f} GB/s algorithmic")
+        print(f"{name:36s} {ms:8.3f} ms   {gb(nbytes, ms):8.0f} GB/s algorithmic")
 
 
 if __name__ == "__main__":
