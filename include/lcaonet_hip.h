@@ -392,14 +392,15 @@ int lcao_geometry_bwd(const float* dist, const float* uvec, const float* g_rb, c
  * differentiate the backward pass again.  Triplet slot t(p,q) = tbase[s] + rank_out(p) * m_in(s) + rank_in(q) with
  * s = src(p) = dst(q); in_rank[q] = rank of q in its node's in-list; n_centres = number of nodes that own out-edges
  * here (all of them, or the owned nodes of a sharded graph; n_edges counts their out-edges for spmm / sddmm and every
- * local edge for spmm_t, whose rows of non-centre targets are zero).  Any V <= 512 (one wave per centre node on fp32
+ * local edge for spmm_t, whose rows of non-centre targets are zero; all_targets_are_centres != 0: the caller states that
+ * there are none — an unsharded graph — and the zero pass over those rows is skipped).  Any V <= 512 (one wave per centre node on fp32
  * MFMA tiles when V % 4 == 0); deterministic. */
 int lcao_trip_spmm(const float* w, const float* A, const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos,
                    const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int V, int n_l,
                    float* out, void* stream);
 int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* dst_p, const int32_t* in_rank, const int32_t* in_ptr,
                      const int32_t* in_pos, const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges,
-                     int64_t n_centres, int V, int n_l, float* out, void* stream);
+                     int64_t n_centres, int V, int n_l, int all_targets_are_centres, float* out, void* stream);
 int lcao_trip_sddmm(const float* G, const float* A, const int32_t* src_p, const int32_t* in_ptr, const int32_t* in_pos,
                     const int32_t* out_ptr, const int64_t* tbase, int64_t n_edges, int64_t n_centres, int V, int n_l,
                     float* out, void* stream);

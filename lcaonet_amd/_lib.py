@@ -78,7 +78,7 @@ SIGNATURES = {
     "lcao_pair_table_grad": [P, P, P, P, P, P, L, I, I, I, P, P],
     "lcao_geometry_bwd": [P, P, P, P, L, I, P, I, I, F, P, P],
     "lcao_trip_spmm": [P, P, P, P, P, P, P, L, L, I, I, P, P],
-    "lcao_trip_spmm_t": [P, P, P, P, P, P, P, P, L, L, I, I, P, P],
+    "lcao_trip_spmm_t": [P, P, P, P, P, P, P, P, L, L, I, I, I, P, P],
     "lcao_trip_sddmm": [P, P, P, P, P, P, P, L, L, I, I, P, P],
     "lcao_trip_weight": [P, P, P, P, P, P, P, L, L, I, P, P],
     "lcao_trip_weight_bwd": [P, P, P, P, P, P, P, P, L, L, I, P, P, P],

@@ -986,7 +986,8 @@ extern "C" int lcao_trip_sddmm(const float* G, const float* A, const int32_t* sr
 
 extern "C" int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* dst_p, const int32_t* in_rank,
                                 const int32_t* in_ptr, const int32_t* in_pos, const int32_t* out_ptr, const int64_t* tbase,
-                                int64_t n_edges, int64_t n_centres, int V, int n_l, float* out, void* stream) {
+                                int64_t n_edges, int64_t n_centres, int V, int n_l, int all_targets_are_centres,
+                                float* out, void* stream) {
   int rc = check_trip(n_edges, V, n_l);
   if (rc != LCAO_OK) return rc;
   if ((rc = check_centres(n_centres)) != LCAO_OK) return rc;
@@ -995,8 +996,9 @@ extern "C" int lcao_trip_spmm_t(const float* w, const float* G, const int32_t* d
   LCAO_CHECK_PTR(in_pos); LCAO_CHECK_PTR(out_ptr); LCAO_CHECK_PTR(tbase); LCAO_CHECK_PTR(out);
   hipStream_t st = (hipStream_t)stream;
   if (V % 4 == 0 && n_centres > 0) {
-    hipLaunchKernelGGL(k_zero_noncentre_rows, dim3(lcao_blocks(n_edges, 4, 65536)), dim3(256), 0, st, dst_p, n_edges,
-                       (int)n_centres, n_l * V, out);
+    if (!all_targets_are_centres)
+      hipLaunchKernelGGL(k_zero_noncentre_rows, dim3(lcao_blocks(n_edges, 4, 65536)), dim3(256), 0, st, dst_p, n_edges,
+                         (int)n_centres, n_l * V, out);
     NODE_DISPATCH(k_trip_spmm_t_node, w, G, in_ptr, in_pos, out_ptr, tbase, (int)n_centres, V, out);
     return lcao_launch_status();
   }

@@ -795,7 +795,7 @@ def trip_spmm_t(w, G, geo):
     c, E = geo.ctx, geo.E
     out = torch.empty(E, n_l, V, device=G.device, dtype=torch.float32)
     _call("lcao_trip_spmm_t", _p(w), _p(G), _p(c.dst_p), _p(geo.in_rank), _p(c.in_ptr), _p(c.in_pos), _p(c.out_ptr),
-          _p(geo.tbase), E, geo.n_own, V, n_l, _p(out), _stream())
+          _p(geo.tbase), E, geo.n_own, V, n_l, int(geo.n_own == geo.N), _p(out), _stream())
     return out
 
 
