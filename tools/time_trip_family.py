@@ -76,6 +76,11 @@ def main():
          E * (row * (2 * L + 3) + 8 * D)),
         ("pair_table_grad", lambda: ops.pair_table_grad(gAg, rb, None, geo.l_of_d, geo.perm_pair, geo.chunk_ptr), E * (row * L + 4 * D)),
     ]
+    Xe, We, Ge = rnd(E, V), rnd(V, V), rnd(E, V)
+    rows += [
+        ("dense (E,V) x (V,V)", lambda: ops.dense(Xe, We), 8 * E * V),
+        ("wgrad (E,V)^T (E,V)", lambda: ops.wgrad(Ge, Xe), 8 * E * V),
+    ]
     for name, fn, nbytes in rows:
         ms = timed(fn, args.iters)
         print(f"{name:36s} {ms:8.3f} ms   {gb(nbytes, ms):8.0f} GB/s algorithmic")
