@@ -1629,7 +1629,7 @@ __device__ __forceinline__ float lcao_wave_sum_dpp(float v) {
   return (a + b) + (c + d);
 }
 
-template <int R, int NL, int DMAX, int LEVEL>
+template <int R, int NL, int DMAX, int LEVEL, bool SWEEP1>   // SWEEP1: the first-order training sweep's operands (order, gram_tri)
 __global__ __launch_bounds__(256) void k_aside_pairs(
     const float* __restrict__ Tf, const float* __restrict__ rb, const int32_t* __restrict__ l_of_d,
     const int64_t* __restrict__ z, const int32_t* __restrict__ src_p, const int32_t* __restrict__ dst_p,
@@ -1662,7 +1662,7 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
     for (int i = i0; i < i1; ++i) {
       const int64_t p = __builtin_amdgcn_readfirstlane(perm[i]);
       const int64_t s = __builtin_amdgcn_readfirstlane(src_p[p]);
-      const int64_t e = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[p]) : p;   // row of rb / d/drb (caller's order)
+      const int64_t e = (SWEEP1 && order) ? (int64_t)__builtin_amdgcn_readfirstlane(order[p]) : p;   // row of rb / d/drb
       float ge[R], hge[R], gb[R], gag[NL][R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -1679,7 +1679,7 @@ __global__ __launch_bounds__(256) void k_aside_pairs(
       for (int l = 0; l < NL; ++l)
 #pragma unroll
         for (int m = 0; m < NL; ++m) {
-          if (gram_tri) {                                  // (E, 10) upper triangle of a 4 x 4 block, Gram coordinates
+          if (SWEEP1 && gram_tri) {                        // (E, 10) upper triangle of a 4 x 4 block, Gram coordinates
             const int lo = l < m ? l : m, hi = l < m ? m : l;
             S[l][m] = gG[p * 10 + lcao_tri_idx(lo, hi)] * (l == m ? 2.0f : 1.0f);
           } else {
@@ -1809,7 +1809,7 @@ extern "C" int lcao_aside_pairs(int level, const float* Tf, const float* rb, con
   LCAO_CHECK_SIZE(n_edges);
   LCAO_CHECK_SIZE(n_chunks);
   if (level < 1 || level > 2 || n_orb <= 0 || n_l < 1 || n_l > LCAO_MAX_L + 1 || zdim <= 0 || V <= 0) return LCAO_ERR_INVALID;
-  if (gram_tri && level != 1) return LCAO_ERR_INVALID;
+  if ((gram_tri || order) && level != 1) return LCAO_ERR_INVALID;
   if (V > 128 || n_orb > 24) return LCAO_ERR_UNSUPPORTED;
   if (n_chunks == 0) return LCAO_OK;
   LCAO_CHECK_PTR(Tf); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p);
@@ -1818,11 +1818,12 @@ extern "C" int lcao_aside_pairs(int level, const float* Tf, const float* rb, con
   if (level == 2) { LCAO_CHECK_PTR(h_rb); LCAO_CHECK_PTR(o_big0); LCAO_CHECK_PTR(o_row0); LCAO_CHECK_PTR(o_gram); }
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(lcao_blocks(n_chunks, 4, 65536)), block(256);
-#define AP_L(R_, NL_, DM_, LV_)                                                                                         \
-  hipLaunchKernelGGL((k_aside_pairs<R_, NL_, DM_, LV_>), grid, block, 0, st, Tf, rb, l_of_d, z, src_p, dst_p, gate, gAg, gB, \
+#define AP_L(R_, NL_, DM_, LV_) { if (order || gram_tri) AP_S(R_, NL_, DM_, LV_, true); else AP_S(R_, NL_, DM_, LV_, false); }
+#define AP_S(R_, NL_, DM_, LV_, S1_)                                                                                    \
+  hipLaunchKernelGGL((k_aside_pairs<R_, NL_, DM_, LV_, S1_>), grid, block, 0, st, Tf, rb, l_of_d, z, src_p, dst_p, gate, gAg, gB, \
                      gG, h_rb, h_gate, perm, chunk_ptr, order, gram_tri, n_chunks, n_orb, V, zdim, o_big0, o_row0, o_gram, o_rb, \
                      o_row1, partial)
-#define AP_D(R_, NL_, DM_) { if (level == 1) AP_L(R_, NL_, DM_, 1); else AP_L(R_, NL_, DM_, 2); return lcao_launch_status(); }
+#define AP_D(R_, NL_, DM_) { if (level == 1) AP_L(R_, NL_, DM_, 1) else AP_S(R_, NL_, DM_, 2, false); return lcao_launch_status(); }
 #define AP_NL(R_, NL_)                                                                                                  \
   if (n_l == NL_) {                                                                                                    \
     if (n_orb <= 8) AP_D(R_, NL_, 8) else if (n_orb <= 16) AP_D(R_, NL_, 16) else AP_D(R_, NL_, 24)                      \
@@ -1833,5 +1834,6 @@ extern "C" int lcao_aside_pairs(int level, const float* Tf, const float* rb, con
 #undef AP_NL
 #undef AP_D
 #undef AP_L
+#undef AP_S
   return LCAO_ERR_INVALID;
 }

@@ -42,25 +42,13 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const float* __restrict__ X,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int64_t n_tiles = (M + 15) >> 4;
-  const int64_t tstep = (int64_t)gridDim.y * 4;
-  f32x4v xn[KT];                                   // the NEXT tile's rows, requested before this tile's MFMAs
-  {
-    const int64_t t0 = (int64_t)blockIdx.y * 4 + wave;
-    const float* xr = X + min(t0 * 16 + r, M - 1) * ldx + 4 * q;
-#pragma unroll
-    for (int a = 0; a < KT; ++a) xn[a] = *(const f32x4v*)(xr + 16 * a);
-  }
-  for (int64_t tile = (int64_t)blockIdx.y * 4 + wave; tile < n_tiles; tile += tstep) {
+  for (int64_t tile = (int64_t)blockIdx.y * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.y * 4) {
     int64_t row = tile * 16 + r;
     bool valid = row < M;
+    const float* xr = X + (valid ? row : M - 1) * ldx + 4 * q;
     f32x4v x[KT];
 #pragma unroll
-    for (int a = 0; a < KT; ++a) x[a] = xn[a];
-    if (tile + tstep < n_tiles) {
-      const float* xr = X + min((tile + tstep) * 16 + r, M - 1) * ldx + 4 * q;
-#pragma unroll
-      for (int a = 0; a < KT; ++a) xn[a] = *(const f32x4v*)(xr + 16 * a);
-    }
+    for (int a = 0; a < KT; ++a) x[a] = *(const f32x4v*)(xr + 16 * a);
     f32x4v acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
