@@ -18,6 +18,10 @@
 
 #include "lcao_mfma.h"
 
+#ifndef TBWD_LINE_STORES
+#define TBWD_LINE_STORES 1
+#endif
+
 // Diagnostic hook (tools/clock_probe.py): when set, lane 0 of every wave of k_coeff_mlp stores
 // {delta s_memtime (shader cycles), delta s_memrealtime (100 MHz ticks)} of its whole tile loop into this buffer
 // (4 x uint64 per wave).  NULL in production: the guarded stamps then never execute.
@@ -1957,26 +1961,43 @@ __device__ __forceinline__ void tbwd_short_in_tile(
           if (it + 4 * r >= m_out) continue;
           const float wr = wl[64 * (t * 4 + r)];
           const int pr = p0 + min(it + 4 * r + quarter, m_out - 1);
-          const float* gtr = g_tbw + (int64_t)pr * V + 4 * n;
+          if constexpr (TBWD_LINE_STORES) {
+            const float* gtr = g_tbw + (int64_t)pr * V + n;
 #pragma unroll
-          for (int h = 0; h < V / 64; ++h) {
-            const f32x4v av = *(const f32x4v*)(gtr + 64 * h);
+            for (int t2 = 0; t2 < KT; ++t2) gA[t2] = MFMA16(gtr[16 * t2], wr, gA[t2]);
+          } else {
+            const float* gtr = g_tbw + (int64_t)pr * V + 4 * n;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gA[4 * h + j] = MFMA16(av[j], wr, gA[4 * h + j]);
+            for (int h = 0; h < V / 64; ++h) {
+              const f32x4v av = *(const f32x4v*)(gtr + 64 * h);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) gA[4 * h + j] = MFMA16(av[j], wr, gA[4 * h + j]);
+            }
           }
         }
       }
       if (qv) {
-        float* go = g_Ag + ((int64_t)q * NL + lm) * V + 16 * quarter;
+        if constexpr (TBWD_LINE_STORES) {
+          float* go = g_Ag + ((int64_t)q * NL + lm) * V + 4 * quarter;
 #pragma unroll
-        for (int h = 0; h < V / 64; ++h)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            f32x4v v = f32x4v{gA[4 * h][rr], gA[4 * h + 1][rr], gA[4 * h + 2][rr], gA[4 * h + 3][rr]};
-            float* dst = go + 64 * h + 4 * rr;
+          for (int t2 = 0; t2 < KT; ++t2) {
+            f32x4v v = gA[t2];
+            float* dst = go + 16 * t2;
             if (ic > 0) v += *(const f32x4v*)dst;
             *(f32x4v*)dst = v;
           }
+        } else {
+          float* go = g_Ag + ((int64_t)q * NL + lm) * V + 16 * quarter;
+#pragma unroll
+          for (int h = 0; h < V / 64; ++h)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              f32x4v v = f32x4v{gA[4 * h][rr], gA[4 * h + 1][rr], gA[4 * h + 2][rr], gA[4 * h + 3][rr]};
+              float* dst = go + 64 * h + 4 * rr;
+              if (ic > 0) v += *(const f32x4v*)dst;
+              *(f32x4v*)dst = v;
+            }
+        }
       }
     }
   }
@@ -2186,7 +2207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
         for (int r = 0; r < 4; ++r) {
           if (it + 4 * r >= m_out) continue;
           const int pr = p0 + min(it + 4 * r + quarter, m_out - 1);
-          if constexpr (V >= 64) {
+          if constexpr (V >= 64 && !TBWD_LINE_STORES) {
             const float* gtr = g_tbw + (int64_t)pr * V + 4 * n;
 #pragma unroll
             for (int h = 0; h < V / 64; ++h) {
@@ -2210,6 +2231,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
           // rows of q: written by the first chunk, added to by later ones (out-lists longer than 16 NITC edges)
           if (qv) {
             static_assert(V >= 64, "the split kernel serves V in {64, 128}");
+            if constexpr (TBWD_LINE_STORES) {
+              // tile t <-> channels 16 t + row: the four quarters of an in-edge write one whole 64-byte line per store
+              float* go = g_Ag + (int64_t)q * NL * V + 4 * quarter;
+#pragma unroll
+              for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int t2 = 0; t2 < KT; ++t2) {
+                  f32x4v v = gA[l][t2];
+                  float* dst = go + l * V + 16 * t2;
+                  if (ic > 0) v += *(const f32x4v*)dst;
+                  *(f32x4v*)dst = v;
+                }
+            } else {
             float* go = g_Ag + (int64_t)q * NL * V + 16 * quarter;
 #pragma unroll
             for (int l = 0; l < NL; ++l)
@@ -2222,6 +2256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LCAO_TBWD_W
                   if (ic > 0) v += *(const f32x4v*)dst;
                   *(f32x4v*)dst = v;
                 }
+            }
           }
         }
       }
