@@ -900,8 +900,11 @@ def _graph_groups(graph, n_groups: int):
     ctx = EdgeContext.build(graph[GraphKeys.Edge_idx], N)
     n_ptr = torch.searchsorted(batch.contiguous(), torch.tensor(g_bounds, device=batch.device, dtype=batch.dtype))
     e_ptr = ctx.out_ptr.long()[n_ptr]                              # p-space is sorted by centre: a node range is an edge range
-    n_b, e_b = torch.stack([n_ptr, e_ptr]).tolist()
-    if any(int(batch[n_b[k]: n_b[k + 1]].numel()) == 0 for k in range(n_groups)):
+    is_sorted = (batch[1:] >= batch[:-1]).all().long().reshape(1).expand(n_groups + 1)
+    n_b, e_b, ok = torch.stack([n_ptr, e_ptr, is_sorted]).tolist()
+    if not ok[0]:
+        raise ValueError("force_training_chunks: the batch index must be sorted (atoms of a graph consecutive)")
+    if any(n_b[k + 1] == n_b[k] for k in range(n_groups)):
         raise ValueError("force_training_chunks: a group of graphs has no atoms")
     order = ctx.order.long()
     idx = graph[GraphKeys.Edge_idx]
