@@ -349,7 +349,8 @@ int lcao_combine_bwd_valence(const float* g_lw, const float* B, const float* Bv,
 /* Fused MFMA forms of the two-body reverse sweep (V in {32, 64, 128}; what torch.autograd does for lcaonet.py:192-213).
  * lcao_message_bwd_fused = lcao_message_bwd + Dense^T(f_node.2) + SiLU'(pre1), pre1 = Ps[src_p] + Pt[dst_p] recomputed:
  *   g_bw = g_agg[src_p] SiLU(pre2);  g_pre2 = g_agg[src_p] bw SiLU'(pre2);  g_pre1 = (g_pre2 Wn2) SiLU'(pre1)
- *   Wn2T = Wn2^T (V,V) contiguous;  g_pre2 (E,V) is written only when non-NULL (weight gradients need it).
+ *   Wn2T = Wn2^T (V,V) contiguous;  g_pre2 (E,V) is written only when non-NULL (weight gradients need it);  g_pre1 NULL:
+ *   only g_bw (and g_pre2) — the first layer of a force sweep, whose node tables do not depend on the positions.
  * lcao_lcao_weight_bwd_fused = Dense^T(basis_weight) + lcao_combine_bwd + Dense^T(f_three):
  *   g_lw = g_bw Wb;  (g_B, g_ft) as lcao_combine_bwd;  g_tbw = g_ft W3;   WbT = Wb^T, W3T = W3^T;  g_ft optional. */
 int lcao_message_bwd_fused(const float* g_agg, const int32_t* src_p, const int32_t* dst_p, const float* bw,
@@ -374,7 +375,7 @@ int lcao_triplet_bwd_mfma(const float* g_tbw, const float* Ag, const float* gram
 int lcao_pair_contract_bwd(const float* Tf, const float* rb, const int32_t* order, const int32_t* l_of_d, const int64_t* z,
                            const int32_t* src_p, const int32_t* dst_p, const float* gate, const float* g_Ag,
                            const float* g_B, const float* g_gram, int64_t n_edges, int64_t e_own, int n_orb, int V, int n_l,
-                           int zdim, float* g_rb /* accumulated */, float* g_gate_part,
+                           int zdim, float* g_rb /* accumulated */, float* g_gate_part /* (E,V) or NULL: not wanted */,
                            float* g_A_out /* (E,n_l,V) or NULL */, void* stream);
 /* training: partial (n_chunks, D, V) sums of rb[e,d] * g_A[p,l(d),:] over chunks of the pair-sorted edge list */
 int lcao_pair_table_grad(const float* g_A, const float* rb, const int32_t* order, const int32_t* l_of_d,

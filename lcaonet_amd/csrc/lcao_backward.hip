@@ -435,7 +435,7 @@ __global__ void k_pair_contract_bwd(const float* __restrict__ Tf, const float* _
         gA[l][r] = v;
         if (g_A_out && l < NL && ch < V) g_A_out[(p * NL + l) * V + ch] = v;
       }
-      if (ch < V) g_gate_part[p * V + ch] = gpart;
+      if (g_gate_part && ch < V) g_gate_part[p * V + ch] = gpart;
     }
     for (int d = 0; d < D; ++d) {
       const int l = l_of_d[d];
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void k_pair_contract_bwd16(
         gA[l][c] = v;
         if (g_A_out && valid && chv) *(f32x4*)(g_A_out + (p * NL + l) * V + off) = v;
       }
-      if (valid && chv) *(f32x4*)(g_gate_part + p * V + off) = gpart;
+      if (g_gate_part && valid && chv) *(f32x4*)(g_gate_part + p * V + off) = gpart;
     }
     if constexpr (DC > 0) {
 #pragma unroll
@@ -585,7 +585,7 @@ extern "C" int lcao_pair_contract_bwd(const float* Tf, const float* rb, const in
   if (n_edges == 0) return LCAO_OK;
   LCAO_CHECK_PTR(Tf); LCAO_CHECK_PTR(rb); LCAO_CHECK_PTR(l_of_d); LCAO_CHECK_PTR(z); LCAO_CHECK_PTR(src_p);
   LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(gate); LCAO_CHECK_PTR(g_Ag); LCAO_CHECK_PTR(g_B); LCAO_CHECK_PTR(g_gram);
-  LCAO_CHECK_PTR(g_rb); LCAO_CHECK_PTR(g_gate_part);
+  LCAO_CHECK_PTR(g_rb);
   dim3 grid(lcao_blocks(n_edges, 4, 65536)), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define PB16(V_, NL_)                                                                                                  \

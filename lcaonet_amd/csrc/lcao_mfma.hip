@@ -1147,6 +1147,7 @@ __global__ __launch_bounds__(256) void k_message_bwd_mfma(
         if (g_pre2_out) *(f32x4v*)(g_pre2_out + p * V + 16 * m + 4 * q) = gp2[m];
       }
     }
+    if (!g_pre1) continue;          // the first layer of a force sweep: its node tables do not depend on positions
     // the node rows of the epilogue (pre1 = Ps[s] + Pt[t]) are requested before the GEMM and land under it
     f32x4v x1[MT];
     {
@@ -1253,7 +1254,7 @@ extern "C" int lcao_message_bwd_fused(const float* g_agg, const int32_t* src_p, 
   if (V <= 0) return LCAO_ERR_INVALID;
   if (n_edges == 0) return LCAO_OK;
   LCAO_CHECK_PTR(g_agg); LCAO_CHECK_PTR(src_p); LCAO_CHECK_PTR(dst_p); LCAO_CHECK_PTR(bw); LCAO_CHECK_PTR(pre2);
-  LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(Wn2T); LCAO_CHECK_PTR(g_bw); LCAO_CHECK_PTR(g_pre1);
+  LCAO_CHECK_PTR(Ps); LCAO_CHECK_PTR(Pt); LCAO_CHECK_PTR(Wn2T); LCAO_CHECK_PTR(g_bw);
   hipStream_t st = (hipStream_t)stream;
   size_t lds = size_t(V) * (V + 4) * sizeof(float);
 #define MB_CASE(V_)                                                                                              \

@@ -86,9 +86,12 @@ def layer_forward_saving(layer, x, Tf_in, rb, uvec_p, ctx, l_of_d, n_l, z, zdim,
 
 
 @torch.no_grad()
-def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tbase, n_trip_dense, g_rb, g_u_p):
+def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tbase, n_trip_dense, g_rb, g_u_p,
+                   first: bool = False):
     """Reverse sweep of one layer: g_xnew = dE/dx_out (n_own rows) -> dE/dx_in (all local rows: owned nodes, then the
-    ghosts of a sharded graph); accumulates dE/drb (orig order) and dE/du (p-space) of every local edge."""
+    ghosts of a sharded graph); accumulates dE/drb (orig order) and dE/du (p-space) of every local edge.
+    first: the first interaction layer — its input x depends on z only, so nothing on the node side (dE/dPs, dE/dPt,
+    dE/dgate, dE/dx) is formed and None is returned."""
     V = layer.emb_size_conv
     E = ctx.n_edges
     n_own, e_own, N = sv["n_own"], sv["e_own"], sv["n_local"]
@@ -101,7 +104,7 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     g_Bv = None
     if V in ops.FUSED_WIDTHS and not layer.add_valence:
         g_bw, g_pre1, _ = ops.message_bwd_fused(g_agg, src_own, dst_own, sv["bw"], sv["pre2"], sv["Ps"], sv["Pt"],
-                                                _t(layer.f_node[2].weight))
+                                                _t(layer.f_node[2].weight), want_g_pre1=not first)
         g_B, g_tbw, _ = ops.lcao_weight_bwd_fused(g_bw, sv["B"], sv["ft"], _t(layer.basis_weight.weight),
                                                   _t(layer.f_three[0].weight))
     else:
@@ -114,10 +117,11 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
         else:
             g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
         g_tbw = ops.dense(g_ft, _t(layer.f_three[0].weight))
-    g_Ps = ops.segment_sum(g_pre1, out_own)              # pre1 = Ps[src] + Pt[dst]
-    if e_own < E:   # ghost-centred edges carry no two-body message: their rows of dE/dpre1 are zero
-        g_pre1 = torch.cat([g_pre1, g_pre1.new_zeros(E - e_own, V)], dim=0)
-    g_Pt = _in_sum(g_pre1, ctx, N)
+    if not first:
+        g_Ps = ops.segment_sum(g_pre1, out_own)              # pre1 = Ps[src] + Pt[dst]
+        if e_own < E:   # ghost-centred edges carry no two-body message: their rows of dE/dpre1 are zero
+            g_pre1 = torch.cat([g_pre1, g_pre1.new_zeros(E - e_own, V)], dim=0)
+        g_Pt = _in_sum(g_pre1, ctx, N)
     # three-body term
     g_Ag, g_gram, g_uq, g_up = ops.triplet_bwd(g_tbw, sv["Ag"], sv["gram"], uvec_p, ctx.src_p, ctx.dst_p, ctx.in_ptr,
                                                ctx.in_pos, ctx.out_ptr, tbase, n_trip_dense, e_own, n_own)
@@ -125,7 +129,7 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     g_u_p += g_up
     # pair-table contraction: A from rb and Tf; Ag = A gate; B; gram
     pcb = lambda T, gA, gB, gG: ops.pair_contract_bwd(T, rb, ctx.order, l_of_d, z, ctx.src_p, ctx.dst_p, sv["gate"], gA, gB,
-                                                      gG, e_own, n_l, zdim, g_rb)
+                                                      gG, e_own, n_l, zdim, g_rb, want_gate=not first)
     if layer.add_valence:
         # A (three-body) comes from Tc + Tv, B from Tc, Bv from Tv: three passes, each adding its part of dE/drb
         Te, Tc, Tv = sv["Tf"]
@@ -135,6 +139,8 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
         pcb(Tv, zA, g_Bv, zG)
     else:
         g_gate_part = pcb(sv["Tf"], g_Ag, g_B, g_gram)
+    if first:
+        return None
     g_gate = ops.segment_sum(g_gate_part, ctx.out_ptr[: N + 1])     # gate[src] of every local edge
     g_xk = ops.act_bwd(g_gate, sv["xk"], ops.ACT_SIGMOID)
     # node level: Ps = xs Wa^T + b (owned), Pt = xs Wb^T (all local) ; [xs | xk] = x Wnw^T + b
@@ -241,8 +247,9 @@ def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
         g_x = ops.dense(ops.act_bwd(g_a, pre_a, ACT), _t(lin[0].weight))
         g_rb = torch.zeros_like(rb)
         g_u_p = torch.zeros(ctx.n_edges, 3, device=pos.device)
-        for layer, sv in zip(reversed(model.int_layers), reversed(saved)):
-            g_x = layer_backward(layer, sv, g_x, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tbase, n_trip_dense, g_rb, g_u_p)
+        for li in reversed(range(len(saved))):
+            g_x = layer_backward(model.int_layers[li], saved[li], g_x, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tbase, n_trip_dense,
+                                 g_rb, g_u_p, first=li == 0)
         # x0 depends on z only.  Geometry: rb = R(dist), u = vec / dist, vec = pos[t] - pos[s] + shift @ lattice
         g_u = torch.empty_like(g_u_p)
         g_u[ctx.order.long()] = g_u_p                       # p-space -> caller's edge order
@@ -341,10 +348,9 @@ def sharded_force_steps(model, plan):
         g_u_p = torch.zeros(ctx.n_edges, 3, device=pos.device)
         for l in reversed(range(L)):
             g_loc = layer_backward(model.int_layers[l], saved[l], g_x, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tbase,
-                                   n_trip_dense, g_rb, g_u_p)
-            g_x = g_loc[:n_own]
+                                   n_trip_dense, g_rb, g_u_p, first=l == 0)
             if l > 0:
-                g_x = g_x + (yield ("reverse", g_loc[n_own:].contiguous()))
+                g_x = g_loc[:n_own] + (yield ("reverse", g_loc[n_own:].contiguous()))
         g_u = torch.empty_like(g_u_p)
         g_u[ctx.order.long()] = g_u_p
         g_vec = ops.geometry_bwd(dist, uvec, g_rb, g_u, model.rbf.orb_table, model.rbf.rbf_kind,

@@ -639,11 +639,12 @@ def edge_two_body_agg(tbw, B, W3, Wb, Ps, Pt, src_p, dst_p, out_ptr, Wn2, bn2, c
 
 
 # --- activation-gradient kernels (autograd forces at inference; csrc/lcao_backward.hip) -------------------------
-def message_bwd_fused(g_agg, src_p, dst_p, bw, pre2, Ps, Pt, Wn2T, want_g_pre2=False):
-    """(g_bw, g_pre1, g_pre2|None): message product, second f_node layer and SiLU'(pre1) differentiated in one kernel."""
+def message_bwd_fused(g_agg, src_p, dst_p, bw, pre2, Ps, Pt, Wn2T, want_g_pre2=False, want_g_pre1=True):
+    """(g_bw, g_pre1|None, g_pre2|None): message product, second f_node layer and SiLU'(pre1) differentiated in one kernel.
+    want_g_pre1=False: g_bw only (the first layer of a force sweep: its node tables do not depend on the positions)."""
     g_agg, bw, pre2, Ps, Pt, Wn2T = _f32(g_agg), _f32(bw), _f32(pre2), _f32(Ps), _f32(Pt), _f32(Wn2T)
     E, V = bw.shape
-    g_bw, g_pre1 = torch.empty_like(bw), torch.empty_like(bw)
+    g_bw, g_pre1 = torch.empty_like(bw), (torch.empty_like(bw) if want_g_pre1 else None)
     g_pre2 = torch.empty_like(bw) if want_g_pre2 else None
     _call("lcao_message_bwd_fused", _p(g_agg), _p(src_p), _p(dst_p), _p(bw), _p(pre2), _p(Ps), _p(Pt), _p(Wn2T), E, V,
           _p(g_bw), _p(g_pre1), _p(g_pre2), _stream())
@@ -728,12 +729,12 @@ def triplet_bwd(g_tbw, Ag, gram, uvec_p, src_p, dst_p, in_ptr, in_pos, out_ptr, 
 
 
 def pair_contract_bwd(Tf, rb, order, l_of_d, z, src_p, dst_p, gate, g_Ag, g_B, g_gram, e_own, n_l, zdim, g_rb,
-                      want_gA: bool = False):
+                      want_gA: bool = False, want_gate: bool = True):
     Tf, rb, gate, g_Ag, g_B, g_gram = _f32(Tf), _f32(rb), _f32(gate), _f32(g_Ag), _f32(g_B), _f32(g_gram)
     z = _i64(z)
     E, D = rb.shape
     V = Tf.shape[-1]
-    g_gate_part = torch.empty(E, V, device=rb.device, dtype=torch.float32)
+    g_gate_part = torch.empty(E, V, device=rb.device, dtype=torch.float32) if want_gate else None
     g_A = torch.empty(E, n_l, V, device=rb.device, dtype=torch.float32) if want_gA else None
     _call("lcao_pair_contract_bwd", _p(Tf), _p(rb), _p(order), _p(l_of_d), _p(z), _p(src_p), _p(dst_p), _p(gate), _p(g_Ag),
           _p(g_B), _p(g_gram), E, e_own, D, V, n_l, zdim, _p(g_rb), _p(g_gate_part), _p(g_A), _stream())
