@@ -98,25 +98,25 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     out_own = ctx.out_ptr[: n_own + 1]
     src_own, dst_own = ctx.src_p[:e_own], ctx.dst_p[:e_own]
     # x' = x + agg Wout^T
-    g_agg = ops.dense(g_xnew, _t(layer.out_weight.weight))
+    wt = layer.transposed_weights()
+    g_agg = ops.dense(g_xnew, wt["out"])
     # msg = bw * silu(pre2), agg = segment sum
     # bw = lw Wb^T ; lw = normalize(B (1 + ft)) ; ft = tbw W3^T
     g_Bv = None
     if V in ops.FUSED_WIDTHS and not layer.add_valence:
         g_bw, g_pre1, _ = ops.message_bwd_fused(g_agg, src_own, dst_own, sv["bw"], sv["pre2"], sv["Ps"], sv["Pt"],
-                                                _t(layer.f_node[2].weight), want_g_pre1=not first)
-        g_B, g_tbw, _ = ops.lcao_weight_bwd_fused(g_bw, sv["B"], sv["ft"], _t(layer.basis_weight.weight),
-                                                  _t(layer.f_three[0].weight))
+                                                wt["node2"], want_g_pre1=not first)
+        g_B, g_tbw, _ = ops.lcao_weight_bwd_fused(g_bw, sv["B"], sv["ft"], wt["basis"], wt["three"])
     else:
         g_bw, g_pre2 = ops.message_bwd(g_agg, src_own, sv["bw"], sv["pre2"])
-        g_h1 = ops.dense(g_pre2, _t(layer.f_node[2].weight))
+        g_h1 = ops.dense(g_pre2, wt["node2"])
         g_pre1 = ops.act_bwd(g_h1, sv["pre1"], ACT)
-        g_lw = ops.dense(g_bw, _t(layer.basis_weight.weight))
+        g_lw = ops.dense(g_bw, wt["basis"])
         if layer.add_valence:
             g_B, g_Bv, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"], sv["Bv"])
         else:
             g_B, g_ft = ops.combine_bwd(g_lw, sv["B"], sv["ft"])
-        g_tbw = ops.dense(g_ft, _t(layer.f_three[0].weight))
+        g_tbw = ops.dense(g_ft, wt["three"])
     if not first:
         g_Ps = ops.segment_sum(g_pre1, out_own)              # pre1 = Ps[src] + Pt[dst]
         if e_own < E:   # ghost-centred edges carry no two-body message: their rows of dE/dpre1 are zero
@@ -144,17 +144,15 @@ def layer_backward(layer, sv, g_xnew, rb, uvec_p, ctx, l_of_d, n_l, z, zdim, tba
     g_gate = ops.segment_sum(g_gate_part, ctx.out_ptr[: N + 1])     # gate[src] of every local edge
     g_xk = ops.act_bwd(g_gate, sv["xk"], ops.ACT_SIGMOID)
     # node level: Ps = xs Wa^T + b (owned), Pt = xs Wb^T (all local) ; [xs | xk] = x Wnw^T + b
-    w1 = layer.f_node[0].weight.detach()
-    g_xs = ops.dense(g_Pt, w1[:, V:].t().contiguous())
-    g_xs_own = ops.dense(g_Ps, w1[:, :V].t().contiguous(), None, ops.ACT_NONE, g_xs[:n_own])
+    g_xs = ops.dense(g_Pt, wt["node1_t"])
+    g_xs_own = ops.dense(g_Ps, wt["node1_s"], None, ops.ACT_NONE, g_xs[:n_own])
     if n_own < N:
         g_xs = torch.cat([g_xs_own, g_xs[n_own:]], dim=0)
         res = torch.cat([g_xnew, g_xnew.new_zeros(N - n_own, g_xnew.shape[1])], dim=0)   # residual path: owned rows
     else:
         g_xs, res = g_xs_own, g_xnew
-    wn = layer.node_weight.weight.detach()
-    g_x = ops.dense(g_xs, wn[:V].t().contiguous(), None, ops.ACT_NONE, res)
-    g_x = ops.dense(g_xk, wn[V:].t().contiguous(), None, ops.ACT_NONE, g_x)
+    g_x = ops.dense(g_xs, wt["nw_s"], None, ops.ACT_NONE, res)
+    g_x = ops.dense(g_xk, wt["nw_k"], None, ops.ACT_NONE, g_x)
     return g_x
 
 

@@ -279,6 +279,24 @@ class LCAOInteraction(nn.Module):
             self.__dict__["_fold"] = (key, w_cat, b_cat)
         return w_cat, b_cat
 
+    def transposed_weights(self) -> dict:
+        """Contiguous transposes of this layer's weights as the reverse sweeps use them (model/forces.py); cached like the
+        folded node weights until a parameter changes."""
+        ps = (self.node_weight.weight, self.f_node[0].weight, self.f_node[2].weight, self.basis_weight.weight,
+              self.f_three[0].weight, self.out_weight.weight)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cached = self.__dict__.get("_wt")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        V = self.emb_size_conv
+        wn, w1, wn2, wb, w3, wout = (p.detach() for p in ps)
+        t = lambda w: w.t().contiguous()
+        wt = {"out": t(wout), "node2": t(wn2), "basis": t(wb), "three": t(w3), "node1_s": t(w1[:, :V]), "node1_t": t(w1[:, V:]),
+              "nw_s": t(wn[:V]), "nw_k": t(wn[V:])}
+        if not torch.cuda.is_current_stream_capturing():
+            self.__dict__["_wt"] = (key, wt)
+        return wt
+
     def _node_level(self, x: Tensor, gate: Tensor, Ps: Tensor | None, Pt: Tensor) -> None:
         """Fill gate / Ps / Pt (row blocks matching x's rows; Ps may be None) — one launch when the widths allow."""
         V, H = self.emb_size_conv, x.shape[1]

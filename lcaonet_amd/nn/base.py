@@ -26,7 +26,7 @@ def act_code(activation: nn.Module | None) -> int | None:
 # Weight-derived caches kept in a module's __dict__ (never in state_dict): LCAOEmbedding's species / pair tables and
 # LCAOInteraction's folded node weights.  They are keyed on (data_ptr, _version) of the tensors they were built from,
 # which an in-place write THROUGH `.data` does not change — so everything that rewrites weights wholesale drops them.
-WEIGHT_CACHE_KEYS = ("_species", "_fold")
+WEIGHT_CACHE_KEYS = ("_species", "_fold", "_wt")
 
 
 def drop_weight_caches(module) -> None:

@@ -1254,6 +1254,29 @@ def test_weight_caches_follow_weight_rewrites(dev):
         m.eval()
         y4 = m(g)
         assert torch.equal(y4, fresh_like(m)(g))
+        # 5. the transposed weights of the force sweep (LCAOInteraction.transposed_weights) follow the same rules: an
+        #    optimiser-style in-place update on the parameter (version bump) and a .data overwrite + invalidate_caches()
+        kwf = dict(kw, regress_forces=True, direct_forces=False)
+
+        def fresh_forces(mf):
+            f = LCAONet(**kwf).to(dev).eval()
+            f.load_state_dict({k: v.clone() for k, v in mf.state_dict().items()})
+            return f(g)
+
+        torch.manual_seed(6)
+        mf = LCAONet(**kwf).to(dev).eval()
+        e0, f0 = mf(g)
+        for p_ in mf.parameters():
+            p_.mul_(1.1)
+        e1, f1 = mf(g)
+        e1r, f1r = fresh_forces(mf)
+        assert not torch.allclose(f0, f1) and torch.equal(e1, e1r) and torch.equal(f1, f1r)
+        for p_ in mf.parameters():
+            p_.data.mul_(0.95)
+        mf.invalidate_caches()
+        e2, f2 = mf(g)
+        e2r, f2r = fresh_forces(mf)
+        assert torch.equal(e2, e2r) and torch.equal(f2, f2r)
 
 
 @pytest.mark.gpu
