@@ -39,13 +39,13 @@ class Data:
     def to(self, *args, **kwargs):
         out = self.__class__()
         for k, v in self._store.items():
-            if k == "_num_graphs_memo":      # tied to one batch tensor (model/base.py::num_graphs)
+            if k.startswith("_") and k.endswith("_memo"):      # tied to one batch tensor (model/base.py::num_graphs, batch_plan)
                 continue
             out._store[k] = v.to(*args, **kwargs) if torch.is_tensor(v) else v
         return out
 
     def to_dict(self):
-        return {k: v for k, v in self._store.items() if k not in ("_num_graphs_memo", "num_graphs")}
+        return {k: v for k, v in self._store.items() if k != "num_graphs" and not (k.startswith("_") and k.endswith("_memo"))}
 
     def __repr__(self):
         items = ", ".join(f"{k}={tuple(v.shape) if torch.is_tensor(v) else v}" for k, v in self._store.items())

@@ -1,6 +1,7 @@
 """BaseMPNN: edge geometry under periodic boundary conditions (reference: lcaonet/model/base.py:10-47)."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -26,6 +27,27 @@ def num_graphs(graph, batch_idx) -> int | None:
     except Exception:  # noqa: BLE001  (a read-only container: pay the sync each call)
         pass
     return n
+
+
+def batch_plan(graph, batch_idx, n_graphs):
+    """The sorted-segment structure of the batch index (nn/scatter.py::index_plan) for the per-graph readout, remembered in
+    the graph for as long as it holds the same batch tensor — the readout, atomref and mean sums of one forward, and every
+    later forward on the same graph, share one sort.  None without a batch index."""
+    from ..nn.scatter import index_plan
+
+    if batch_idx is None:
+        return None
+    tag = (batch_idx.data_ptr(), batch_idx._version, batch_idx.numel(), n_graphs)
+    memo = graph.get("_batch_plan_memo") if hasattr(graph, "get") else None
+    if memo is not None and memo[0] == tag:
+        return memo[1]
+    plan = index_plan(batch_idx, n_graphs)
+    if not torch.cuda.is_current_stream_capturing():     # tensors made inside a capture live in the graph's pool
+        try:
+            graph["_batch_plan_memo"] = (tag, plan)
+        except Exception:  # noqa: BLE001  (a read-only container: sort on each call)
+            pass
+    return plan
 
 
 class BaseMPNN(nn.Module):

@@ -173,7 +173,7 @@ def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
     tables = (x_tab (max_z+1, H), cst_pair, zdim): embedding tables supplied by the caller (model/train.py: train-mode
     BatchNorm batch statistics) instead of the eval-mode ones."""
     from .lcaonet import EdgeContext
-    from .base import BaseMPNN, num_graphs
+    from .base import BaseMPNN, batch_plan, num_graphs
 
     try:
         _check_supported(model, tables is not None)
@@ -218,14 +218,15 @@ def forward_with_autograd_forces(model, graph, tables=None, ctx=None):
     prop = ops.dense(b, lin[4].weight.detach())
     n_graphs = num_graphs(graph, batch_idx)
     red = "sum" if model.out_layer.is_extensive else "mean"
+    plan = batch_plan(graph, batch_idx, n_graphs)
     if batch_idx is not None:
-        out = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce=red)
-        cnt = scatter(torch.ones(N, 1, device=prop.device), batch_idx, dim=0, dim_size=out.shape[0])[:, 0].clamp(min=1)
+        out = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce=red, plan=plan)
+        cnt = (plan[1][1:] - plan[1][:-1]).clamp(min=1).to(prop.dtype)           # atoms per graph
         node_scale = torch.ones(N, device=prop.device) if red == "sum" else (1.0 / cnt)[batch_idx]
     else:
         out = prop.sum(0, keepdim=True) if red == "sum" else prop.mean(0, keepdim=True)
         node_scale = torch.full((N,), 1.0 if red == "sum" else 1.0 / N, device=prop.device)
-    out = model.pp_layer(out, z, batch_idx, n_graphs)     # atomref / mean: no position dependence
+    out = model.pp_layer(out, z, batch_idx, n_graphs, batch_plan=plan)     # atomref / mean: no position dependence
 
     # dense per-node scratch layout for the per-triplet dE/dcos
     m_in = (ctx.in_ptr[1:] - ctx.in_ptr[:-1]).long()

@@ -38,7 +38,7 @@ from ..nn.rbf import BaseRadialBasis
 from ..nn.scatter import csr_ptr, scatter
 from ..nn.shbf import SphericalHarmonicsBasis
 from ..utils.resolve import activation_resolver, cutoffnet_resolver, init_resolver, rbf_resolver
-from .base import BaseMPNN, num_graphs
+from .base import BaseMPNN, batch_plan, num_graphs
 
 
 @dataclass
@@ -457,10 +457,11 @@ class LCAOOut(nn.Module):
 
     @inference_only
     def forward(self, x: Tensor, batch_idx: Tensor | None, idx_s: Tensor, idx_t: Tensor, edge_vec_st: Tensor,
-                pos: Tensor, n_graphs: int | None = None):
+                pos: Tensor, n_graphs: int | None = None, batch_plan=None):
         prop = run_mlp(self.out_lin, x)
         if batch_idx is not None:
-            prop = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce="sum" if self.is_extensive else "mean")
+            prop = scatter(prop, batch_idx, dim=0, dim_size=n_graphs, reduce="sum" if self.is_extensive else "mean",
+                           plan=batch_plan if n_graphs is not None else None)
         else:
             prop = prop.sum(0, keepdim=True) if self.is_extensive else prop.mean(0, keepdim=True)
         if not self.regress_forces:
@@ -800,5 +801,6 @@ class LCAONet(BaseMPNN):
                 trace[f"three_body_w{i + 1}"] = tr["three_body_w"]
 
         n_graphs = num_graphs(graph, batch_idx)      # B = batch.max() + 1 as lcaonet.py:292, without a per-call sync
-        out = self.out_layer(x, batch_idx, idx_s, idx_t, uvec, pos, n_graphs)
-        return self.pp_layer(out, z, batch_idx, n_graphs)
+        plan = batch_plan(graph, batch_idx, n_graphs)   # one sort of the batch index per graph, shared by the three sums below
+        out = self.out_layer(x, batch_idx, idx_s, idx_t, uvec, pos, n_graphs, batch_plan=plan)
+        return self.pp_layer(out, z, batch_idx, n_graphs, batch_plan=plan)

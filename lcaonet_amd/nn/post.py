@@ -19,7 +19,7 @@ class PostProcess(nn.Module):
     def extra_repr(self) -> str:
         return f"is_extensive={self.is_extensive}, atomref={self.atomref}, mean={self.mean}"
 
-    def forward(self, out, z: Tensor, batch_idx: Tensor | None, n_graphs: int | None = None):
+    def forward(self, out, z: Tensor, batch_idx: Tensor | None, n_graphs: int | None = None, batch_plan=None):
         out, force = out if isinstance(out, tuple) else (out, None)
         red = "sum" if self.is_extensive else "mean"
         if self.atomref is not None:
@@ -27,14 +27,16 @@ class PostProcess(nn.Module):
             if batch_idx is None:
                 aref = aref.sum(0, keepdim=True) if self.is_extensive else aref.mean(0, keepdim=True)
             else:
-                aref = scatter(aref, batch_idx, dim=0, dim_size=n_graphs, reduce=red)
+                aref = scatter(aref, batch_idx, dim=0, dim_size=n_graphs, reduce=red,
+                               plan=batch_plan if n_graphs is not None else None)
             out = out + aref
         if self.mean is not None:
             mean = self.mean.unsqueeze(0)
             if self.is_extensive:
                 mean = mean.expand(z.size(0), -1)
                 mean = mean.sum(0, keepdim=True) if batch_idx is None else \
-                    scatter(mean.contiguous(), batch_idx, dim=0, dim_size=n_graphs, reduce="sum")
+                    scatter(mean.contiguous(), batch_idx, dim=0, dim_size=n_graphs, reduce="sum",
+                            plan=batch_plan if n_graphs is not None else None)
             out = out + mean
         if force is not None:
             return out, force

@@ -38,17 +38,23 @@ def _segment_sum_two_level(rows: Tensor, ptr: Tensor, dim_size: int, chunk: int 
     return ops.segment_sum(partial, torch.clamp(cptr, max=total).to(torch.int32))
 
 
-def scatter(src: Tensor, index: Tensor, dim: int = 0, dim_size: int | None = None, reduce: str = "sum") -> Tensor:
+def index_plan(index: Tensor, dim_size: int):
+    """(order, ptr): the stable argsort of `index` (int32) and the segment bounds of the sorted list — what `scatter` builds
+    from an index on every call; callers that reduce over the same index repeatedly (the per-graph readout over the batch
+    index) build it once and pass it as `plan`."""
+    order = torch.argsort(index, stable=True)
+    return order.to(torch.int32), csr_ptr(index[order], dim_size)
+
+
+def scatter(src: Tensor, index: Tensor, dim: int = 0, dim_size: int | None = None, reduce: str = "sum", plan=None) -> Tensor:
     if dim != 0:
         raise NotImplementedError("scatter: the path only reduces along dim 0")
     if dim_size is None:
         dim_size = int(index.max().item()) + 1 if index.numel() > 0 else 0  # host sync, as torch_scatter does
     tail = src.shape[1:]
     src2 = src.reshape(src.shape[0], -1) if src.dim() != 2 else src
-    order = torch.argsort(index, stable=True)
-    sorted_idx = index[order]
-    rows = ops.gather_rows(src2.float().contiguous(), order.to(torch.int32))
-    ptr = csr_ptr(sorted_idx, dim_size)
+    order, ptr = plan if plan is not None else index_plan(index, dim_size)
+    rows = ops.gather_rows(src2.float().contiguous(), order)
     if dim_size > 0 and rows.shape[0] > LONG_SEGMENT * dim_size:
         out = _segment_sum_two_level(rows, ptr, dim_size)
     else:
