@@ -103,6 +103,33 @@ __global__ void k_dense_valu(const float* __restrict__ X, int64_t ldx, const flo
   }
 }
 
+// Few output columns (the last layer of the output head: out_size = 1 or 2): 16 lanes per row, each lane a float4 stride of
+// the row, one DPP row reduction per column — the lanes-over-columns fallback above leaves 63 of 64 lanes idle there.
+__global__ __launch_bounds__(256) void k_dense_narrow(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ R,
+                                                      int64_t ldr, float* __restrict__ Y, int64_t ldy, int64_t M, int K,
+                                                      int N, int act) {
+  const int sub = threadIdx.x & 15;
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t rc = row < M ? row : M - 1;
+  const float* xr = X + rc * ldx;
+  for (int n = 0; n < N; ++n) {
+    const float* wr = W + (int64_t)n * K;
+    float acc = 0.f;
+    for (int k = 4 * sub; k < K; k += 64) {
+      const f32x4v x = *(const f32x4v*)(xr + k), w = *(const f32x4v*)(wr + k);
+      acc += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+    }
+    acc = lcao_row16_sum(acc);
+    if (sub == 0 && row < M) {
+      if (bias) acc += bias[n];
+      acc = lcao_act(acc, act);
+      if (R) acc += R[row * ldr + n];
+      Y[row * ldy + n] = acc;
+    }
+  }
+}
+
 template <int KT>
 static int launch_dense_mfma(const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                              int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int act, hipStream_t st) {
@@ -146,6 +173,11 @@ extern "C" int lcao_dense(const float* X, int64_t ldx, const float* W, const flo
       default: break;
     }
 #undef DENSE_CASE
+  }
+  if (N <= 4 && K % 4 == 0 && ldx % 4 == 0 && (uintptr_t)X % 16 == 0 && (uintptr_t)W % 16 == 0) {
+    hipLaunchKernelGGL(k_dense_narrow, dim3(lcao_blocks(M, 16)), dim3(256), 0, st, X, ldx, W, bias, residual, ldr, Y, ldy,
+                       M, K, N, act);
+    return lcao_launch_status();
   }
   hipLaunchKernelGGL(k_dense_valu, dim3(lcao_blocks(M, 4, 65536)), dim3(256), 0, st, X, ldx, W, bias, residual, ldr,
                      Y, ldy, M, K, N, act);
