@@ -81,6 +81,58 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const float* __restrict__ X,
   }
 }
 
+// N % 128 == 0 and many rows: one workgroup of 8 waves owns 128 output columns (weights = 128 x (K + 4) floats of LDS, two
+// workgroups per CU) and every X row is read once; the next tile's rows are requested into the operand registers as soon as
+// the GEMM has consumed them, so they are in flight under the epilogue and the stores (as in k_edge_lcao_weight).
+template <int KT>
+__global__ __launch_bounds__(512) void k_dense_mfma_wide(const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         const float* __restrict__ R, int64_t ldr, float* __restrict__ Y,
+                                                         int64_t ldy, int64_t M, int N, int act) {
+  constexpr int K = KT * 16;
+  extern __shared__ float lds[];
+  const int n0 = blockIdx.x * 128;
+  stage_weights(lds, W + (int64_t)n0 * K, 128, K, K);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (M + 15) >> 4;
+  const int64_t stride = (int64_t)gridDim.y * 8;
+  int64_t tile = (int64_t)blockIdx.y * 8 + wave;
+  f32x4v x[KT];
+  if (tile < n_tiles) {
+    const float* xr = X + min(tile * 16 + r, M - 1) * ldx + 4 * q;
+#pragma unroll
+    for (int a = 0; a < KT; ++a) x[a] = *(const f32x4v*)(xr + 16 * a);
+  }
+  for (; tile < n_tiles; tile += stride) {
+    asm volatile("" ::: "memory");
+    const int64_t row = tile * 16 + r;
+    const bool valid = row < M;
+    f32x4v acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    mfma_layer<KT, 8>(lds, K + 4, r, q, x, acc);
+    if (tile + stride < n_tiles) {
+      const float* xr = X + min((tile + stride) * 16 + r, M - 1) * ldx + 4 * q;
+#pragma unroll
+      for (int a = 0; a < KT; ++a) x[a] = *(const f32x4v*)(xr + 16 * a);
+    }
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int n = n0 + 16 * t + 4 * q;
+        f32x4v v = acc[t];
+        if (bias) v += *(const f32x4v*)(bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = lcao_act(v[j], act);
+        if (R) v += *(const f32x4v*)(R + row * ldr + n);
+        *(f32x4v*)(Y + row * ldy + n) = v;
+      }
+    }
+  }
+}
+
 // VALU fallback for arbitrary K, N (tiny heads like out_size = 1, odd widths in the reference's tests):
 // one wave per output row, lanes over output columns, X row broadcast from L1.
 __global__ void k_dense_valu(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
@@ -134,6 +186,24 @@ template <int KT>
 static int launch_dense_mfma(const float* X, int64_t ldx, const float* W, const float* bias, const float* R,
                              int64_t ldr, float* Y, int64_t ldy, int64_t M, int N, int act, hipStream_t st) {
   constexpr int K = KT * 16;
+  if constexpr (KT <= 8) if (N % 128 == 0 && M >= 16384) {   // wide form: whole 128-column slices, X rows read once
+    const size_t lds_w = size_t(128) * (K + 4) * sizeof(float);
+    static bool attr_w = false;
+    if (!attr_w && lds_w > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_dense_mfma_wide<KT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_w);
+      if (e != hipSuccess) return int(e);
+      attr_w = true;
+    }
+    const int nsl = N / 128;
+    int64_t groups = ((M + 15) / 16 + 7) / 8;
+    int64_t cap = (int64_t)lcao_num_cu() * 2 / nsl;
+    if (cap < 1) cap = 1;
+    if (groups > cap) groups = cap;
+    hipLaunchKernelGGL(k_dense_mfma_wide<KT>, dim3(nsl, (unsigned)groups), dim3(512), lds_w, st, X, ldx, W, bias, R, ldr,
+                       Y, ldy, M, N, act);
+    return lcao_launch_status();
+  }
   size_t lds = size_t(64) * (K + 4) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {

@@ -101,6 +101,9 @@ def test_basis_edge_cases(dev):
     (1000, 128, 128, 1, True, False), (37, 128, 256, 0, True, True), (515, 64, 32, 2, False, False),
     (64, 16, 32, 1, True, False), (33, 48, 96, 0, False, True), (129, 256, 64, 1, True, False),
     (50, 10, 20, 1, True, False), (7, 8, 1, 0, False, False), (100, 20, 10, 2, True, True), (0, 16, 16, 0, True, False),
+    # many rows, N % 128 == 0: the 128-column workgroup form; few output columns: the 16-lanes-per-row form
+    (16384 + 77, 128, 128, 1, True, True), (20001, 64, 256, 0, False, False), (16390, 96, 128, 2, True, False),
+    (5003, 64, 1, 0, False, False), (4100, 128, 2, 1, True, True), (999, 32, 4, 0, True, False),
 ])
 def test_dense(dev, M, K, N, act, bias, res):
     from lcaonet_amd import ops
