@@ -427,7 +427,7 @@ def main():
 
     secondary_error = None
     pair_ms = bf_ms = bp_ms = pair_err = bf_err = bp_err = forces_ms = train_ms = ftrain_ms = mat_ms = mat_err = h_ms = h_err = None
-    roof_bf = roof_h = roof_forces = roof_train = roof_ftrain = None
+    roof_bf = roof_h = roof_forces = roof_train = roof_ftrain = replay = None
     D_, C_, V_, NL_ = model.elec_info.n_orb, model.emb_size_coeff, model.emb_size_conv, model.n_l
     mlp_flop = 2.0 * D_ * (C_ * V_ + V_ * V_)
     # algorithmic work per edge of the kernels that dominate the secondary modes
@@ -471,6 +471,19 @@ def main():
                     roof_bf = mode_roofline(lambda: model(batch, precision="bf16x3"), 3, mode_work, E)
                     roof_h = mode_roofline(lambda: model(batch, precision="f16"), 3, mode_work, E)
                 bp_ms, bp_err = timed(precision="bf16x3", cst_mode="pair")
+            if not with_forces:
+                # the same forward replayed as ONE HIP graph (model/capture.py: the MD inner loop between neighbour-list
+                # rebuilds — positions change, the edge list and its CSR do not)
+                from lcaonet_amd.model import CapturedForward
+                cap = CapturedForward(model, batch)
+                cap_err = float((cap(batch["pos"]) - out).abs().max() / out.abs().max())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    cap(batch["pos"])
+                torch.cuda.synchronize()
+                replay = (1e3 * (time.perf_counter() - t1) / args.steps, cap_err)
+                del cap
             if not with_forces and args.workload == "cfg2":
                 # rows f3 of SURVEY.md 8: energy + autograd forces (reverse sweep) and one full training step, same batch
                 fm = build_model(dict(model_kw, regress_forces=True, direct_forces=False), 1234, dev)
@@ -631,6 +644,12 @@ def main():
                 "note": "NOT the headline: LCAONet.forward(cst_mode='pair') — f_coeffs evaluated on the (z_s,z_t) species-pair "
                         "table (SURVEY.md 8f-2) instead of per edge; same outputs", "ms_per_step_rank0": round(pair_ms, 3),
                 "edges_per_s_rank0": E / (pair_ms * 1e-3), "max_rel_diff_vs_headline_output": pair_err}
+        if replay is not None:
+            line["hip_graph_replay_mode"] = {
+                "note": "NOT the headline: the whole forward captured once (CapturedForward) and replayed with the positions "
+                        "copied in — fixed edge list, so lcao_build_csr (0.19 ms) is outside the replay; no launch gaps",
+                "ms_per_step_rank0": round(replay[0], 3), "edges_per_s_rank0": E / (replay[0] * 1e-3),
+                "max_rel_diff_vs_headline_output": replay[1]}
         if secondary_error is not None:
             line["secondary_error"] = secondary_error
         if bf_ms is not None:
