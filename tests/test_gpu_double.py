@@ -435,7 +435,7 @@ def test_fused_level_maps_first_and_second_derivatives(dev):
         got = chain(lambda x, y: _SiluMulFn.apply(x, y), [a, b], R, Hs)
         want = chain(lambda x, y: x * F.silu(y), dbl([a, b]), dbl(R), dbl(Hs))
         assert all(relerr(g_, w_) <= 5e-6 for g_, w_ in zip(got, want)), ("silumul", E, V)
-    for V, max_z in ((32, 10), (64, 36), (128, 36), (64, 2)):            # n_l = 2, 3, 3, 1
+    for V, max_z in ((32, 10), (64, 36), (128, 36), (64, 2), (64, 56), (32, 96)):   # n_l = 2, 3, 3, 1, 3, 4; D = 3 .. 18
         g = random_periodic_cells(2, 11, 6.0, 0.99 * 4.5, seed=3, max_z=max_z).to(dev)
         m = LCAONet(emb_size=16, emb_size_coeff=16, emb_size_conv=V, n_interaction=1, cutoff=4.5, max_z=max_z).to(dev)
         geo = _Geo(m, g)
