@@ -554,8 +554,12 @@ extern "C" int lcao_coeff_mlp_contract(const float* cst, const float* rb, const 
   CM_CASE(128, 128)
   CM_CASE(64, 64)
   CM_CASE(32, 32)
-  CM_CASE(64, 128)   // emb_size_coeff != emb_size_conv: the two common mixed widths
+  CM_CASE(64, 128)   // emb_size_coeff != emb_size_conv: every pair of {32, 64, 128}
   CM_CASE(128, 64)
+  CM_CASE(32, 64)
+  CM_CASE(64, 32)
+  CM_CASE(32, 128)
+  CM_CASE(128, 32)
 #undef CM_CASE
   return rc;
 }

@@ -14,7 +14,7 @@ CUTOFF_KINDS = {"envelope": 0, "polynomial": 1, "cosine": 2, "none": 3}
 RBF_KINDS = {"hydrogen": 0, "bessel": 1}
 ORB_STRIDE = 12
 FUSED_WIDTHS = (32, 64, 128)
-FUSED_COEFF_SHAPES = ((128, 128), (64, 64), (32, 32), (64, 128), (128, 64))   # (C, V) built into lcao_coeff_mlp_contract
+FUSED_COEFF_SHAPES = tuple((c, v) for c in (32, 64, 128) for v in (32, 64, 128))   # (C, V) built into lcao_coeff_mlp_contract
 
 
 def _p(t: Tensor | None):

@@ -386,7 +386,7 @@ def test_sharded_forward_hip_matches_unsharded(dev, world, cells):
     assert relerr(total, full) <= 2e-6
 
 
-@pytest.mark.parametrize("C,V", [(64, 128), (128, 64)])
+@pytest.mark.parametrize("C,V", [(64, 128), (128, 64), (32, 64), (64, 32), (32, 128), (128, 32)])
 def test_fused_path_mixed_coeff_and_conv_widths(dev, C, V):
     """emb_size_coeff != emb_size_conv on the fused MFMA kernels (lcao_coeff_mlp_contract<C, V>) against the oracle."""
     from lcaonet_amd.data.synthetic import random_periodic_cells
